@@ -1,0 +1,181 @@
+"""The CPU oracle against the golden vectors produced by the reference (CPU only)."""
+import hashlib
+import json
+
+import numpy as np
+import pytest
+
+from conftest import SAMPLES, golden, load_sample, unpack, zmin_from_centi
+from oracle import smrf_oracle as orc
+
+
+def sha(a):
+    return hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_disk_known_sizes():
+    # card(disk(r))
+    for r, card in ((0, 1), (1, 5), (2, 13), (3, 29), (5, 81), (10, 317), (18, 1009), (25, 1961), (50, 7845)):
+        assert int(orc.disk(r).sum()) == card
+    assert sum(int(orc.disk(r).sum()) for r in range(1, 19)) == 6582
+    assert sum(int(orc.disk(r).sum()) for r in range(1, 51)) == 134478
+
+
+def test_affine_samp11_cs0p3():
+    t = orc.from_origin(512699.55, 5403850.65, 0.3, 0.3)
+    inv = ~t
+    assert inv[0] == 3.3333333333333335 or inv[0] == 3.333333333333333
+    assert tuple(t[6:]) == (0.0, 0.0, 1.0)
+
+
+PF = golden("progressive_filter.npz")
+
+
+@pytest.mark.parametrize("tag", [str(c) for c in PF["cases"]])
+def test_progressive_filter_golden(tag):
+    Z = PF[tag + "_Z"]
+    windows = PF[tag + "_windows"]
+    cellsize, slope = PF[tag + "_params"]
+    if cellsize == int(cellsize):
+        cellsize = int(cellsize)
+    mask, wd = orc.progressive_filter(Z, windows, cellsize, slope, return_when_dropped=True)
+    assert mask.dtype == bool and wd.dtype == np.uint8
+    assert np.array_equal(mask, unpack(PF[tag + "_mask_bits"], Z.shape))
+    assert np.array_equal(wd, PF[tag + "_when_dropped"])
+    last = Z.copy()
+    for i, w in enumerate(windows):
+        last = orc.opening(last, orc.disk(int(w)))
+        assert sha(last) == str(PF[tag + "_opened_sha1"][i])
+    assert np.array_equal(last, PF[tag + "_opened_last"], equal_nan=True)
+
+
+INP = golden("inpaint.npz")
+
+
+@pytest.mark.parametrize("tag", [str(c) for c in INP["cases"]])
+def test_inpaint_golden(tag):
+    A = INP[tag + "_in"]
+    want = INP[tag + "_out"]
+    istop, itn = INP[tag + "_lsqr"]
+    A0 = A.copy()
+    got, gi, gn = orc.inpaint_nans_by_springs(A, return_info=True)
+    assert np.array_equal(A, A0, equal_nan=True)          # input untouched
+    assert (gi, gn) == (int(istop), int(itn))
+    assert not np.isnan(got).any()
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-9)
+    assert np.array_equal(got[~np.isnan(A)], A[~np.isnan(A)])
+    A2 = A.copy()
+    assert orc.inpaint_nans_by_springs(A2, inplace=True) is None
+    assert np.array_equal(A2, got)
+
+
+def test_lsqr_restatement_matches_scipy_lsqr():
+    """The matrix-free restatement against scipy.sparse.linalg.lsqr on the explicit matrix."""
+    from scipy import sparse
+    from scipy.sparse.linalg import lsqr
+    rng = np.random.default_rng(3)
+    A = rng.normal(100, 3, (37, 29))
+    A[rng.random(A.shape) < 0.7] = np.nan
+    m, n = A.shape
+    hole = np.isnan(A)
+    idx = np.arange(m * n).reshape(m, n)
+    lo = np.concatenate([idx[:, :-1].ravel(), idx[:-1, :].ravel()])
+    hi = np.concatenate([idx[:, 1:].ravel(), idx[1:, :].ravel()])
+    act = hole.ravel()[lo] | hole.ravel()[hi]
+    lo, hi = lo[act], hi[act]
+    order = np.lexsort((hi, lo))
+    lo, hi = lo[order], hi[order]
+    ns = lo.size
+    S = sparse.coo_matrix((np.r_[np.ones(ns), -np.ones(ns)], (np.r_[np.arange(ns), np.arange(ns)], np.r_[lo, hi])),
+                          (ns, m * n)).tocsr()
+    known = np.flatnonzero(~hole.ravel())
+    nanl = np.flatnonzero(hole.ravel())
+    rhs = -S[:, known] * A.ravel()[known]
+    out = lsqr(S[:, nanl], rhs)
+    got, istop, itn = orc.lsqr_springs(A)
+    assert (istop, itn) == (out[1], out[2])
+    np.testing.assert_allclose(got.ravel()[nanl], out[0], rtol=0, atol=1e-10)
+
+
+CD = golden("create_dem.npz")
+
+
+@pytest.mark.parametrize("tag", [str(c) for c in CD["cases"]])
+def test_create_dem_golden(tag):
+    kw = json.loads(str(CD[tag + "_kwargs_json"]))
+    if kw.get("edges"):
+        kw["edges"] = (CD[tag + "_xedges"], CD[tag + "_yedges"])
+    I, t = orc.create_dem(CD[tag + "_x"], CD[tag + "_y"], CD[tag + "_z"], **kw)
+    want = CD[tag + "_I"]
+    assert I.shape == want.shape and I.dtype == np.float64
+    assert np.array_equal(t[:6], CD[tag + "_transform"])
+    if kw.get("inpaint"):
+        np.testing.assert_allclose(I, want, rtol=0, atol=1e-9)
+    else:
+        assert np.array_equal(I, want, equal_nan=True)
+
+
+def test_create_dem_errors():
+    with pytest.raises(ValueError, match="This type not supported."):
+        orc.create_dem(np.array([0., 1.]), np.array([0., 1.]), np.array([0., 1.]), bin_type="mean")
+    with pytest.raises(ValueError):
+        orc.create_dem(np.array([1.5, 3.0]), np.array([1.5, 2.5]), np.array([1.0, 2.0]),
+                       edges=(np.arange(0.0, 4.0), np.arange(3.0, -1.0, -1.0)))
+
+
+META = json.load(open(__import__("os").path.join(__import__("conftest").GOLDEN, "meta.json")))
+
+
+def check_smrf_against(gold, x, y, z, kw, full, stride):
+    Zpro, t, obj, pts, extras, st = orc.smrf(x, y, z, return_extras=True, return_stages=True, **kw)
+    shape = tuple(gold["shape"])
+    assert Zpro.shape == shape
+    assert np.array_equal(t[:6], gold["transform"])
+    assert np.array_equal(st["Zmin"], zmin_from_centi(gold["Zmin_centi"]), equal_nan=True)
+    assert st["lsqr1"] == tuple(gold["lsqr1"]) and st["lsqr2"] == tuple(gold["lsqr2"])
+    assert np.array_equal(st["low_outliers"], unpack(gold["low_outliers_bits"], shape))
+    assert np.array_equal(st["pf_mask"], unpack(gold["pf_mask_bits"], shape))
+    assert np.array_equal(st["pf_when_dropped"], gold["pf_when_dropped"])
+    assert np.array_equal(obj, unpack(gold["object_cells_bits"], shape))
+    assert np.array_equal(pts, unpack(gold["is_object_point_bits"], pts.shape))
+    assert np.array_equal(extras["when_dropped"], gold["when_dropped_pts"])
+    for key, val in (("inpaint1", st["inpaint1"]), ("Zpro", Zpro), ("elevation_values", st["elevation_values"]),
+                     ("slope_values", st["slope_values"]), ("above_ground_height", extras["above_ground_height"])):
+        if full:
+            np.testing.assert_allclose(val, gold[key], rtol=0, atol=1e-8)
+        else:
+            np.testing.assert_allclose(val.ravel()[::stride], gold[key + "_strided"], rtol=0, atol=1e-8)
+        assert abs(float(np.sum(val)) - float(gold[key + "_sum"][0])) < 1e-5
+    return pts
+
+
+@pytest.mark.parametrize("name", SAMPLES)
+def test_smrf_samples_golden(name):
+    x, y, z, g = load_sample(name)
+    gold = golden("smrf_%s.npz" % name)
+    pts = check_smrf_against(gold, x, y, z, META["smrf_kwargs"], name in META["full_dtm"], META["stride"])
+    err = 100.0 * (1.0 - np.mean(pts == g))
+    assert abs(err - META["anchors"][name]["total_error_pct"]) < 1e-9
+
+
+@pytest.mark.parametrize("tag", ["cs2", "lowfill", "winlist"])
+def test_smrf_samp11_variants(tag):
+    x, y, z, g = load_sample("samp11")
+    gold = golden("smrf_samp11_%s.npz" % tag)
+    kw = json.loads(str(gold["kwargs_json"]))
+    if isinstance(kw["windows"], list):
+        kw["windows"] = np.array(kw["windows"])
+    check_smrf_against(gold, x, y, z, kw, False, META["stride"])
+
+
+def test_samp12_published_numbers():
+    """The reference notebook prints these four figures for samp12 (ipynb :902-905)."""
+    x, y, z, g = load_sample("samp12")
+    pts = orc.smrf(x, y, z, **META["smrf_kwargs"])[3]
+    g = g.astype(bool)
+    type1 = 100.0 * np.sum(~g & pts) / np.sum(g)
+    type2 = 100.0 * np.sum(g & ~pts) / np.sum(~g)
+    total = 100.0 * (1 - np.sum(pts == g) / len(g))
+    assert abs(type1 - 2.00566304861) < 5e-12
+    assert abs(type2 - 4.12498595032) < 5e-12
+    assert abs(total - 3.09100328095) < 5e-12
