@@ -1,0 +1,180 @@
+/*
+ * smrf_hip.h -- C ABI of libsmrf_hip.so: the MI355X (gfx950) implementation of neilpy's
+ * SMRF bare-earth path.
+ *
+ * The reference (thomaspingel/neilpy) is a pure-Python function library with no FFI of its
+ * own; the interfaces this library replaces are therefore the Python callables of the path
+ * and the third-party primitives they dispatch to.  Each entry point cites what it replaces
+ * (paths relative to the reference checkout):
+ *
+ *   smrf_disk_filter_*        skimage.morphology.erosion/dilation with disk(r) as reached by
+ *                             opening(last_surface, disk(window)), neilpy/neilpy.py:1670
+ *                             (-> scipy.ndimage.grey_erosion/grey_dilation, mode='reflect')
+ *   smrf_progressive_filter_* progressive_filter(), neilpy/neilpy.py:1659-1680
+ *   smrf_points_extent_f64,
+ *   smrf_grid_*               create_dem(), neilpy/neilpy.py:1110-1166 (pandas groupby min/max
+ *                             at :1151-1156, affine index arithmetic at :1141-1143)
+ *   smrf_springs_lsqr_f64     inpaint_nans_by_springs(), neilpy/neilpy.py:1227-1271, whose
+ *                             solve is scipy.sparse.linalg.lsqr (:1264)
+ *   smrf_gradient_slope_f64   np.gradient + sqrt, neilpy/neilpy.py:1785-1786
+ *   smrf_negate_f64, smrf_mask_apply_f64
+ *                             the elementwise glue of smrf(), neilpy/neilpy.py:1744, :1748, :1762-1763
+ *
+ * Conventions
+ *   - every pointer named d_* is DEVICE memory (hipMalloc or a torch CUDA tensor's data_ptr);
+ *     h_* is host memory.  The library never allocates or frees caller-visible memory; scratch
+ *     comes from the caller through (workspace, workspace_bytes).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Unless stated, calls
+ *     only enqueue work on `stream` and return without synchronising.
+ *   - return value: 0 on success, a negative SMRF_E_* code on failure; smrf_last_error() gives
+ *     a human-readable message for the calling thread.  No exceptions cross the boundary.
+ *   - rasters are row-major, row 0 = north, `ld` = elements between consecutive rows.
+ *   - there is no CPU fallback: without a HIP device every compute entry returns SMRF_E_HIP.
+ */
+#ifndef SMRF_HIP_H
+#define SMRF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMRF_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define SMRF_API __attribute__((visibility("default")))
+#else
+#define SMRF_API
+#endif
+
+#define SMRF_OK 0
+#define SMRF_E_ARG (-1)       /* invalid argument (null pointer, bad size, band does not cover halo) */
+#define SMRF_E_HIP (-2)       /* a HIP runtime call failed, or no device */
+#define SMRF_E_WORKSPACE (-3) /* workspace too small */
+#define SMRF_E_RANGE (-4)     /* a point falls outside the grid (create_dem with edges=) */
+#define SMRF_E_UNSUPPORTED (-5)
+
+/* implementation selector for the disk filter (tests exercise both; 0 is the product default) */
+#define SMRF_IMPL_AUTO 0
+#define SMRF_IMPL_RING 1   /* register-ring kernels, radius 1..SMRF_RING_MAX_RADIUS */
+#define SMRF_IMPL_DIRECT 2 /* footprint-gather kernel, any radius */
+#define SMRF_RING_MAX_RADIUS 64
+
+SMRF_API int smrf_abi_version(void);
+SMRF_API const char* smrf_last_error(void);
+/* number of visible HIP devices (0 when there is none); never fails */
+SMRF_API int smrf_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Grey erosion / dilation by skimage's disk(radius) with scipy's mode='reflect' borders.
+ *
+ * The raster has `img_rows` x `cols` cells.  `d_in` holds global rows
+ * [in_row0, in_row0+in_rows), `d_out` receives global rows [out_row0, out_row0+out_rows);
+ * both pointers address the first row they hold.  Single GPU: in_row0 = out_row0 = 0 and
+ * in_rows = out_rows = img_rows.  Row-band sharding: every row reflect(y) for
+ * y in [out_row0-radius, out_row0+out_rows+radius) must lie inside the input band
+ * (otherwise SMRF_E_ARG).
+ *
+ * nan_aware != 0 reproduces scipy's NaN rule (the result is NaN iff the first visited
+ * footprint element, offset (-radius, 0), is NaN; other NaNs are ignored); 0 assumes the input
+ * has no NaN and skips the extra read.
+ * ------------------------------------------------------------------------------------------ */
+SMRF_API int smrf_disk_filter_f32(const float* d_in, float* d_out, int img_rows, int cols, int64_t ld,
+                         int in_row0, int in_rows, int out_row0, int out_rows, int radius,
+                         int is_dilate, int nan_aware, int impl, void* stream);
+SMRF_API int smrf_disk_filter_f64(const double* d_in, double* d_out, int img_rows, int cols, int64_t ld,
+                         int in_row0, int in_rows, int out_row0, int out_rows, int radius,
+                         int is_dilate, int nan_aware, int impl, void* stream);
+
+/* One progressive_filter step after the erosion: opened = dilate(eroded, disk(radius)), then
+ *   new_obj = (double)(last - opened) > threshold   (subtraction in the raster dtype,
+ *   comparison in float64: NumPy-2 promotion of neilpy.py:1671)
+ *   mask |= new_obj;  when_dropped[new_obj] = window_index   (d_when_dropped may be NULL)
+ * d_last, d_opened, d_mask, d_when_dropped address global row out_row0. */
+SMRF_API int smrf_pf_dilate_flag_f32(const float* d_eroded, const float* d_last, float* d_opened,
+                            uint8_t* d_mask, uint8_t* d_when_dropped, double threshold,
+                            int window_index, int img_rows, int cols, int64_t ld, int in_row0,
+                            int in_rows, int out_row0, int out_rows, int radius, int nan_aware,
+                            int impl, void* stream);
+SMRF_API int smrf_pf_dilate_flag_f64(const double* d_eroded, const double* d_last, double* d_opened,
+                            uint8_t* d_mask, uint8_t* d_when_dropped, double threshold,
+                            int window_index, int img_rows, int cols, int64_t ld, int in_row0,
+                            int in_rows, int out_row0, int out_rows, int radius, int nan_aware,
+                            int impl, void* stream);
+
+/* Whole progressive_filter on one device.  d_Z is read only.  h_windows / h_thresholds are HOST
+ * arrays of n_windows entries; thresholds are slope_threshold*(windows*cellsize) evaluated by
+ * the caller in float64 (neilpy.py:1661).  d_mask (rows*cols bytes, 0/1) and d_when_dropped
+ * (may be NULL) are overwritten.  Workspace: smrf_progressive_filter_workspace_bytes().
+ * nan_aware < 0: the library counts NaNs itself (one small synchronising readback). */
+SMRF_API size_t smrf_progressive_filter_workspace_bytes(int rows, int cols, int elem_size);
+SMRF_API int smrf_progressive_filter_f32(const float* d_Z, int rows, int cols, const int32_t* h_windows,
+                                const double* h_thresholds, int n_windows, uint8_t* d_mask,
+                                uint8_t* d_when_dropped, void* d_workspace,
+                                size_t workspace_bytes, int nan_aware, int impl, void* stream);
+SMRF_API int smrf_progressive_filter_f64(const double* d_Z, int rows, int cols, const int32_t* h_windows,
+                                const double* h_thresholds, int n_windows, uint8_t* d_mask,
+                                uint8_t* d_when_dropped, void* d_workspace,
+                                size_t workspace_bytes, int nan_aware, int impl, void* stream);
+
+/* number of NaN cells of a contiguous array, written to *h_count (synchronises `stream`) */
+SMRF_API int smrf_count_nan_f32(const float* d_a, int64_t n, int64_t* h_count, void* stream);
+SMRF_API int smrf_count_nan_f64(const double* d_a, int64_t n, int64_t* h_count, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * create_dem
+ * ------------------------------------------------------------------------------------------ */
+/* h_out[4] = min x, max x, min y, max y over n points (synchronises `stream`).
+ * workspace: 4 * 1024 doubles. */
+SMRF_API int smrf_points_extent_f64(const double* d_x, const double* d_y, int64_t n, double* h_out,
+                           void* d_workspace, size_t workspace_bytes, void* stream);
+/* keys: one uint64 per cell; all-ones = empty */
+SMRF_API int smrf_grid_clear_u64(uint64_t* d_keys, int64_t ncells, void* stream);
+/* col = floor(x*inv[0] + y*inv[1] + inv[2]), row = floor(x*inv[3] + y*inv[4] + inv[5]) with
+ * separately rounded multiplies and adds (no FMA), inv = coefficients (a,b,c,d,e,f) of the
+ * inverse affine transform.  Points with NaN z are skipped (pandas min/max skip NaN).
+ * h_filter (may be NULL) = {xedges[0], xedges[-1], yedges[-1], yedges[0]}: points outside are
+ * dropped first (neilpy.py:1128).  Rows [row0, row0+rows_local) of the rows_total x cols grid
+ * are held in d_keys (row-band sharding; single GPU: row0 = 0, rows_local = rows_total);
+ * points of other bands are ignored, points outside the whole grid are counted in
+ * *d_n_outside (device int64, caller zeroes it). */
+SMRF_API int smrf_grid_bin_f64(const double* d_x, const double* d_y, const double* d_z, int64_t npts,
+                      const double* h_inv, const double* h_filter, uint64_t* d_keys,
+                      int rows_total, int cols, int row0, int rows_local, int is_max,
+                      int64_t* d_n_outside, void* stream);
+/* keys -> float64 grid, empty -> NaN; d_empty (may be NULL) gets 1 where empty */
+SMRF_API int smrf_grid_finalize_f64(const uint64_t* d_keys, double* d_grid, uint8_t* d_empty,
+                           int64_t ncells, int is_max, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * inpaint_nans_by_springs: matrix-free LSQR on the raster's edge planes, scipy's recurrence
+ * and stopping rule (damp = 0).  d_A (rows x cols, contiguous, float64) is updated in place:
+ * NaN cells receive the solution, known cells are untouched.  iter_lim < 0 -> 2*n_unknown.
+ * Synchronous: returns after the solve; *h_istop, *h_itn as scipy reports them.
+ * ------------------------------------------------------------------------------------------ */
+SMRF_API size_t smrf_springs_workspace_bytes(int rows, int cols);
+SMRF_API int smrf_springs_lsqr_f64(double* d_A, int rows, int cols, double atol, double btol,
+                          double conlim, int64_t iter_lim, int* h_istop, int64_t* h_itn,
+                          int64_t* h_n_unknown, void* d_workspace, size_t workspace_bytes,
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * smrf tail
+ * ------------------------------------------------------------------------------------------ */
+/* S = sqrt(gy^2 + gx^2), (gy, gx) = np.gradient(Z, cellsize) (second-order interior,
+ * first-order one-sided edges).  rows, cols >= 2. */
+SMRF_API int smrf_gradient_slope_f64(const double* d_Z, double* d_S, int rows, int cols, double cellsize,
+                            void* stream);
+
+/* out = -in (smrf runs the low-outlier filter on -Zmin, neilpy.py:1744) */
+SMRF_API int smrf_negate_f64(const double* d_in, double* d_out, int64_t n, void* stream);
+/* u = a | b | c (b, c, d_union may be NULL); Z[u] = NaN  (neilpy.py:1748 and :1762-1763) */
+SMRF_API int smrf_mask_apply_f64(double* d_Z, const uint8_t* d_a, const uint8_t* d_b, const uint8_t* d_c,
+                        uint8_t* d_union, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMRF_HIP_H */

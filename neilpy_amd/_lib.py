@@ -1,0 +1,84 @@
+"""ctypes binding of libsmrf_hip.so (the C ABI declared in include/smrf_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, an exception is
+raised.  Build the library with ``python -m neilpy_amd.build`` (or ``__graft_entry__.build()``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libsmrf_hip.so")
+
+IMPL_AUTO, IMPL_RING, IMPL_DIRECT = 0, 1, 2
+RING_MAX_RADIUS = 64
+
+
+class SmrfHipError(RuntimeError):
+    pass
+
+
+_p = C.c_void_p
+_i = C.c_int
+_i64 = C.c_int64
+_d = C.c_double
+_sz = C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/smrf_hip.h one to one
+SIGNATURES = {
+    "smrf_abi_version": (_i, []),
+    "smrf_last_error": (C.c_char_p, []),
+    "smrf_device_count": (_i, []),
+    "smrf_disk_filter_f32": (_i, [_p, _p, _i, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "smrf_disk_filter_f64": (_i, [_p, _p, _i, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "smrf_pf_dilate_flag_f32": (_i, [_p, _p, _p, _p, _p, _d, _i, _i, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "smrf_pf_dilate_flag_f64": (_i, [_p, _p, _p, _p, _p, _d, _i, _i, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "smrf_progressive_filter_workspace_bytes": (_sz, [_i, _i, _i]),
+    "smrf_progressive_filter_f32": (_i, [_p, _i, _i, _p, _p, _i, _p, _p, _p, _sz, _i, _i, _p]),
+    "smrf_progressive_filter_f64": (_i, [_p, _i, _i, _p, _p, _i, _p, _p, _p, _sz, _i, _i, _p]),
+    "smrf_count_nan_f32": (_i, [_p, _i64, C.POINTER(_i64), _p]),
+    "smrf_count_nan_f64": (_i, [_p, _i64, C.POINTER(_i64), _p]),
+    "smrf_points_extent_f64": (_i, [_p, _p, _i64, C.POINTER(_d), _p, _sz, _p]),
+    "smrf_grid_clear_u64": (_i, [_p, _i64, _p]),
+    "smrf_grid_bin_f64": (_i, [_p, _p, _p, _i64, C.POINTER(_d), C.POINTER(_d), _p, _i, _i, _i, _i, _i, _p, _p]),
+    "smrf_grid_finalize_f64": (_i, [_p, _p, _p, _i64, _i, _p]),
+    "smrf_springs_workspace_bytes": (_sz, [_i, _i]),
+    "smrf_springs_lsqr_f64": (_i, [_p, _i, _i, _d, _d, _d, _i64, C.POINTER(_i), C.POINTER(_i64),
+                                   C.POINTER(_i64), _p, _sz, _p]),
+    "smrf_gradient_slope_f64": (_i, [_p, _p, _i, _i, _d, _p]),
+    "smrf_negate_f64": (_i, [_p, _p, _i64, _p]),
+    "smrf_mask_apply_f64": (_i, [_p, _p, _p, _p, _p, _i64, _p]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the library once and attach the prototypes; raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SmrfHipError(
+            "libsmrf_hip.so is not built (%s missing). Run `python -m neilpy_amd.build`; "
+            "neilpy_amd has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.smrf_abi_version() != 1:
+        raise SmrfHipError("libsmrf_hip ABI version %d, expected 1" % lib.smrf_abi_version())
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().smrf_last_error().decode("utf-8", "replace")
+        raise SmrfHipError("libsmrf_hip error %d: %s" % (rc, msg))
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available() or load().smrf_device_count() < 1:
+        raise SmrfHipError("no HIP device visible: neilpy_amd runs on MI355X only (no CPU fallback)")

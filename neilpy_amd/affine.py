@@ -1,0 +1,54 @@
+"""Affine transform returned by create_dem / smrf.
+
+The reference returns ``rasterio.transform.from_origin(...)``, an ``affine.Affine``
+(neilpy.py:1141).  When the ``affine`` package is importable its class is used, so callers get
+the very same type; otherwise this module's 9-tuple with the same arithmetic is used.
+"""
+
+try:  # pragma: no cover - depends on the environment
+    from affine import Affine as _ExternalAffine
+except Exception:  # noqa: BLE001
+    _ExternalAffine = None
+
+
+class Affine(tuple):
+    """(a, b, c, d, e, f, 0, 0, 1): x' = a*x + b*y + c, y' = d*x + e*y + f."""
+
+    def __new__(cls, a, b, c, d, e, f):
+        return tuple.__new__(cls, (a, b, c, d, e, f, 0.0, 0.0, 1.0))
+
+    a = property(lambda s: s[0])
+    b = property(lambda s: s[1])
+    c = property(lambda s: s[2])
+    d = property(lambda s: s[3])
+    e = property(lambda s: s[4])
+    f = property(lambda s: s[5])
+
+    @property
+    def determinant(self):
+        return self[0] * self[4] - self[1] * self[3]
+
+    def __invert__(self):
+        sa, sb, sc, sd, se, sf = self[:6]
+        idet = 1.0 / (sa * se - sb * sd)
+        ra, rb, rd, re = se * idet, -sb * idet, -sd * idet, sa * idet
+        return Affine(ra, rb, -sc * ra - sf * rb, rd, re, -sc * rd - sf * re)
+
+    def __mul__(self, other):
+        sa, sb, sc, sd, se, sf = self[:6]
+        if isinstance(other, Affine):
+            oa, ob, oc, od, oe, of = other[:6]
+            return Affine(sa * oa + sb * od, sa * ob + sb * oe, sa * oc + sb * of + sc,
+                          sd * oa + se * od, sd * ob + se * oe, sd * oc + se * of + sf)
+        vx, vy = other
+        return (vx * sa + vy * sb + sc, vx * sd + vy * se + sf)
+
+    def __repr__(self):
+        return "Affine(%r, %r, %r,\n       %r, %r, %r)" % tuple(self[:6])
+
+
+def from_origin(west, north, xsize, ysize):
+    """rasterio.transform.from_origin: translation(west, north) * scale(xsize, -ysize)."""
+    if _ExternalAffine is not None:
+        return _ExternalAffine.translation(west, north) * _ExternalAffine.scale(xsize, -ysize)
+    return Affine(1.0, 0.0, west, 0.0, 1.0, north) * Affine(xsize, 0.0, 0.0, 0.0, -ysize, 0.0)

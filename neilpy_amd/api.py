@@ -1,0 +1,366 @@
+"""Host side of the SMRF path: neilpy's call signatures over libsmrf_hip (MI355X only).
+
+Mirrors, argument for argument, the reference functions (paths relative to the reference
+checkout): ``create_dem`` (neilpy/neilpy.py:1110), ``inpaint_nans_by_springs`` (:1227),
+``progressive_filter`` (:1659), ``smrf`` (:1685) and the skimage seam they use, ``disk`` /
+``opening`` (:43-44, :1670).  Build-specific options are keyword-only and come last.
+
+NumPy in -> NumPy out; ``torch`` CUDA tensor in -> CUDA tensor out (no host copy).  All compute
+runs in hand-written HIP kernels behind the C ABI of ``include/smrf_hip.h``; PyTorch only owns
+device memory and the stream.  There is no CPU fallback: without the library or a GPU every
+function raises :class:`neilpy_amd.SmrfHipError`.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .affine import from_origin
+
+__all__ = ["disk", "erosion", "dilation", "opening", "progressive_filter", "create_dem",
+           "inpaint_nans_by_springs", "smrf", "last_stats"]
+
+#: statistics of the most recent calls (LSQR istop / itn, unknown counts), SURVEY section 5
+last_stats = {}
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _stream():
+    return C.c_void_p(_torch().cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _is_tensor(a):
+    return type(a).__module__.startswith("torch") and hasattr(a, "data_ptr")
+
+
+def _to_device(a, dtype=None):
+    """NumPy / tensor -> contiguous CUDA tensor (float32 and float64 kept, others -> float64)."""
+    torch = _torch()
+    _lib.require_gpu()
+    if _is_tensor(a):
+        t = a
+    else:
+        arr = np.asarray(a)
+        if dtype is None and arr.dtype not in (np.float32, np.float64):
+            arr = arr.astype(np.float64)
+        t = torch.from_numpy(np.ascontiguousarray(arr))
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    if t.dtype not in (torch.float32, torch.float64):
+        t = t.to(torch.float64)
+    if not t.is_cuda:
+        t = t.cuda()
+    return t.contiguous()
+
+
+def _suffix(t):
+    return "f32" if t.dtype == _torch().float32 else "f64"
+
+
+# ------------------------------------------------------------------------------------------
+# disk / erosion / dilation / opening  (skimage.morphology as used at neilpy.py:1667-1670)
+# ------------------------------------------------------------------------------------------
+def disk(radius, dtype=np.uint8):
+    """skimage.morphology.disk: ``x*x + y*y <= radius*radius`` on a (2r+1)^2 grid."""
+    L = np.arange(-radius, radius + 1)
+    X, Y = np.meshgrid(L, L)
+    return np.array((X ** 2 + Y ** 2) <= radius ** 2, dtype=dtype)
+
+
+def _radius_of(footprint, radius):
+    if radius is not None:
+        return int(radius)
+    fp = np.asarray(footprint)
+    if fp.ndim != 2 or fp.shape[0] != fp.shape[1] or fp.shape[0] % 2 != 1:
+        raise NotImplementedError("only skimage disk(r) footprints are supported on the device")
+    r = fp.shape[0] // 2
+    if not np.array_equal(fp != 0, disk(r) != 0):
+        raise NotImplementedError("only skimage disk(r) footprints are supported on the device")
+    return r
+
+
+def _has_nan(t):
+    lib = _lib.load()
+    cnt = C.c_int64(0)
+    _lib.check(getattr(lib, "smrf_count_nan_" + _suffix(t))(_ptr(t), t.numel(), C.byref(cnt), _stream()))
+    return cnt.value > 0
+
+
+def _disk_filter(image, radius, dilate, impl, nan_aware=None):
+    torch = _torch()
+    was_tensor = _is_tensor(image)
+    src = _to_device(image)
+    if src.dim() != 2:
+        raise ValueError("expected a 2-D raster")
+    rows, cols = src.shape
+    if rows == 0 or cols == 0:
+        out = src.clone()
+        return out if was_tensor else out.cpu().numpy()
+    if nan_aware is None:
+        nan_aware = _has_nan(src)
+    out = torch.empty_like(src)
+    lib = _lib.load()
+    fn = getattr(lib, "smrf_disk_filter_" + _suffix(src))
+    _lib.check(fn(_ptr(src), _ptr(out), rows, cols, cols, 0, rows, 0, rows, int(radius), int(bool(dilate)),
+                  int(bool(nan_aware)), int(impl), _stream()))
+    return out if was_tensor else out.cpu().numpy()
+
+
+def erosion(image, footprint=None, *, radius=None, impl=_lib.IMPL_AUTO):
+    """Grey erosion by ``disk(r)``, borders ``mode='reflect'`` (scipy.ndimage.grey_erosion)."""
+    return _disk_filter(image, _radius_of(footprint, radius), False, impl)
+
+
+def dilation(image, footprint=None, *, radius=None, impl=_lib.IMPL_AUTO):
+    """Grey dilation by ``disk(r)``, borders ``mode='reflect'`` (scipy.ndimage.grey_dilation)."""
+    return _disk_filter(image, _radius_of(footprint, radius), True, impl)
+
+
+def opening(image, footprint=None, *, radius=None, impl=_lib.IMPL_AUTO):
+    """skimage.morphology.opening(image, disk(r)) = dilation(erosion(image))."""
+    r = _radius_of(footprint, radius)
+    was_tensor = _is_tensor(image)
+    src = _to_device(image)
+    nan_aware = _has_nan(src) if src.numel() else False
+    e = _disk_filter(src, r, False, impl, nan_aware)
+    o = _disk_filter(e, r, True, impl, nan_aware)
+    return o if was_tensor else o.cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------
+# progressive_filter  (neilpy.py:1659-1680)
+# ------------------------------------------------------------------------------------------
+def _progressive_filter_device(Zd, windows, thresholds, want_when, impl=_lib.IMPL_AUTO, nan_aware=-1):
+    """Device-resident core: CUDA raster in, (uint8 mask, uint8 when_dropped | None) CUDA out."""
+    torch = _torch()
+    lib = _lib.load()
+    rows, cols = Zd.shape
+    mask = torch.empty((rows, cols), dtype=torch.uint8, device=Zd.device)
+    when = torch.empty((rows, cols), dtype=torch.uint8, device=Zd.device) if want_when else None
+    if rows == 0 or cols == 0:
+        return mask, when
+    win = np.ascontiguousarray(np.asarray(windows).astype(np.int32))
+    thr = np.ascontiguousarray(np.asarray(thresholds, dtype=np.float64))
+    if win.ndim != 1 or thr.shape != win.shape:
+        raise ValueError("windows must be a 1-D array")
+    nbytes = lib.smrf_progressive_filter_workspace_bytes(rows, cols, Zd.element_size())
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=Zd.device)
+    fn = getattr(lib, "smrf_progressive_filter_" + _suffix(Zd))
+    _lib.check(fn(_ptr(Zd), rows, cols, win.ctypes.data_as(C.c_void_p), thr.ctypes.data_as(C.c_void_p),
+                  int(win.size), _ptr(mask), _ptr(when), _ptr(ws), nbytes, int(nan_aware), int(impl), _stream()))
+    return mask, when
+
+
+def progressive_filter(Z, windows, cellsize=1, slope_threshold=.15, return_when_dropped=False, *,
+                       impl=_lib.IMPL_AUTO):
+    """Iterative grey opening with growing disks and slope-scaled thresholds -> object mask.
+
+    Same arguments, results and quirks as neilpy.progressive_filter: ``windows`` is an array of
+    integer radii, ``disk(window)`` is used for every window (also window 1), ``when_dropped``
+    holds the 0-based index of the last window that flagged the cell, ``Z`` is not modified.
+    """
+    elevation_thresholds = slope_threshold * (windows * cellsize)         # neilpy.py:1661 verbatim
+    was_tensor = _is_tensor(Z)
+    Zd = _to_device(Z)
+    if Zd.dim() != 2:
+        raise ValueError("expected a 2-D raster")
+    if len(windows) > 256 and return_when_dropped:
+        raise OverflowError("when_dropped is uint8: more than 256 windows overflow it (as in the reference)")
+    mask, when = _progressive_filter_device(Zd, windows, elevation_thresholds, return_when_dropped, impl)
+    if was_tensor:
+        mask = mask.bool()
+        return (mask, when) if return_when_dropped else mask
+    m = mask.cpu().numpy().astype(bool)
+    return (m, when.cpu().numpy()) if return_when_dropped else m
+
+
+# ------------------------------------------------------------------------------------------
+# create_dem  (neilpy.py:1110-1166)
+# ------------------------------------------------------------------------------------------
+def _create_dem_device(xd, yd, zd, cellsize, bin_type, edges):
+    """Device core: returns (float64 grid CUDA tensor, uint8 empty mask CUDA tensor, transform)."""
+    torch = _torch()
+    lib = _lib.load()
+    npts = xd.numel()
+    h_filter = None
+    if edges is None:
+        if npts == 0:
+            raise ValueError("zero-size array to reduction operation minimum which has no identity")
+        ws = torch.empty(4 * 1024, dtype=torch.float64, device=xd.device)
+        ext = (C.c_double * 4)()
+        _lib.check(lib.smrf_points_extent_f64(_ptr(xd), _ptr(yd), npts, ext, _ptr(ws), ws.numel() * 8, _stream()))
+        xmin, xmax, ymin, ymax = (np.float64(v) for v in ext)
+        xedges = np.arange(cellsize * np.floor(xmin / cellsize) - .5 * cellsize,
+                           cellsize * np.ceil(xmax / cellsize) + 1.5 * cellsize, cellsize)
+        yedges = np.arange(cellsize * np.ceil(ymax / cellsize) + .5 * cellsize,
+                           cellsize * np.floor(ymin / cellsize) - 1.5 * cellsize, -cellsize)
+    else:
+        xedges, yedges = edges[0], edges[1]
+        h_filter = (C.c_double * 4)(float(xedges[0]), float(xedges[-1]), float(yedges[-1]), float(yedges[0]))
+        cellsize = np.abs(xedges[1] - xedges[0])
+    nx, ny = len(xedges) - 1, len(yedges) - 1
+    t = from_origin(xedges[0], yedges[0], cellsize, cellsize)
+    inv = ~t
+    h_inv = (C.c_double * 6)(*[float(v) for v in tuple(inv)[:6]])
+    is_max = 1 if bin_type == 'max' else 0
+    keys = torch.empty((max(ny, 0), max(nx, 0)), dtype=torch.int64, device=xd.device)
+    n_out = torch.zeros(1, dtype=torch.int64, device=xd.device)
+    grid = torch.empty((max(ny, 0), max(nx, 0)), dtype=torch.float64, device=xd.device)
+    empty = torch.empty((max(ny, 0), max(nx, 0)), dtype=torch.uint8, device=xd.device)
+    if nx < 1 or ny < 1:
+        if npts:
+            raise ValueError("invalid entry in coordinates array")
+        return grid, empty, t
+    _lib.check(lib.smrf_grid_clear_u64(_ptr(keys), keys.numel(), _stream()))
+    _lib.check(lib.smrf_grid_bin_f64(_ptr(xd), _ptr(yd), _ptr(zd), npts, h_inv, h_filter, _ptr(keys), ny, nx, 0, ny,
+                                     is_max, _ptr(n_out), _stream()))
+    if int(n_out.item()) > 0:
+        raise ValueError("invalid entry in coordinates array")       # np.ravel_multi_index, neilpy.py:1151
+    if bin_type not in ('max', 'min'):
+        raise ValueError('This type not supported.')                  # neilpy.py:1158
+    _lib.check(lib.smrf_grid_finalize_f64(_ptr(keys), _ptr(grid), _ptr(empty), keys.numel(), is_max, _stream()))
+    return grid, empty, t
+
+
+def _points_to_device(x, y, z):
+    torch = _torch()
+    xd = _to_device(x if _is_tensor(x) else np.asarray(x, dtype=np.float64), torch.float64).reshape(-1)
+    yd = _to_device(y if _is_tensor(y) else np.asarray(y, dtype=np.float64), torch.float64).reshape(-1)
+    zd = _to_device(z if _is_tensor(z) else np.asarray(z, dtype=np.float64), torch.float64).reshape(-1)
+    if not (xd.numel() == yd.numel() == zd.numel()):
+        raise ValueError("x, y and z must have the same length")
+    return xd, yd, zd
+
+
+def create_dem(x, y, z, cellsize=1, bin_type='max', inpaint=False, edges=None, use_binned_statistic=False):
+    """Grid (x, y, z) points to a min-/max-Z raster; empty cells are NaN.  Returns ``(I, t)``.
+
+    Same arguments and results as neilpy.create_dem (float64 grid, row 0 = north, affine
+    transform ``t``).  ``use_binned_statistic=True`` is the reference's acknowledged-broken
+    branch (:1148-1149) and is not provided.
+    """
+    if use_binned_statistic:
+        raise NotImplementedError("use_binned_statistic=True (neilpy.py:1148) is not supported")
+    was_tensor = _is_tensor(x)
+    xd, yd, zd = _points_to_device(x, y, z)
+    grid, _, t = _create_dem_device(xd, yd, zd, cellsize, bin_type, edges)
+    if inpaint == True:  # noqa: E712  (the reference's own test, :1163)
+        _springs_device(grid)
+    return (grid if was_tensor else grid.cpu().numpy()), t
+
+
+# ------------------------------------------------------------------------------------------
+# inpaint_nans_by_springs  (neilpy.py:1227-1271)
+# ------------------------------------------------------------------------------------------
+def _springs_device(Ad, key="inpaint"):
+    """In-place LSQR spring fill of a contiguous float64 CUDA raster; returns (istop, itn)."""
+    torch = _torch()
+    lib = _lib.load()
+    rows, cols = Ad.shape
+    if rows == 0 or cols == 0:
+        return 0, 0
+    nbytes = lib.smrf_springs_workspace_bytes(rows, cols)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=Ad.device)
+    istop, itn, nunk = C.c_int(0), C.c_int64(0), C.c_int64(0)
+    _lib.check(lib.smrf_springs_lsqr_f64(_ptr(Ad), rows, cols, 1e-6, 1e-6, 1e8, -1, C.byref(istop), C.byref(itn),
+                                         C.byref(nunk), _ptr(ws), nbytes, _stream()))
+    last_stats[key] = dict(istop=istop.value, itn=itn.value, n_unknown=nunk.value)
+    return istop.value, itn.value
+
+
+def inpaint_nans_by_springs(A, inplace=False, neighbors=4):
+    """Fill NaNs by least-squares springs to the 4 neighbours, stopped where SciPy's LSQR stops.
+
+    Same arguments and results as neilpy.inpaint_nans_by_springs (``neighbors`` is accepted and
+    ignored there too); ``inplace=True`` writes into ``A`` and returns ``None``.
+    """
+    torch = _torch()
+    if _is_tensor(A):
+        if A.dtype != torch.float64:
+            raise TypeError("inpaint_nans_by_springs works in float64, as the reference does")
+        work = A if (inplace and A.is_cuda and A.is_contiguous()) else _to_device(A).clone()
+        _springs_device(work)
+        if inplace:
+            if work is not A:
+                A.copy_(work)
+            return None
+        return work
+    arr = np.asarray(A)
+    if arr.ndim != 2:
+        raise ValueError("expected a 2-D raster")
+    work = _to_device(arr.astype(np.float64, copy=False), torch.float64).clone()
+    _springs_device(work)
+    out = work.cpu().numpy()
+    if inplace:
+        A[...] = out
+        return None
+    return out.astype(arr.dtype, copy=False) if arr.dtype == np.float64 else out
+
+
+# ------------------------------------------------------------------------------------------
+# smrf  (neilpy.py:1685-1808)
+# ------------------------------------------------------------------------------------------
+def smrf(x, y, z, cellsize=1, windows=5, slope_threshold=.15, elevation_threshold=.5,
+         elevation_scaler=1.25, low_filter_slope=5, low_outlier_fill=False,
+         return_extras=False):
+    """Simple Morphological Filter: returns ``(dtm, transform, object_grid, object_vector[, extras])``.
+
+    Same arguments, defaults and results as neilpy.smrf.  Gridding, both inpaints, both
+    progressive filters and the slope raster run on the GPU with the rasters resident in HBM
+    between stages; the bicubic spline evaluation of the tail (:1768-1790) is SciPy's FITPACK on
+    the host, as in the reference ("what comes next").
+    """
+    torch = _torch()
+    from scipy import interpolate
+    if np.isscalar(windows):
+        windows = np.arange(windows) + 1
+    xd, yd, zd = _points_to_device(x, y, z)
+    Zmin, empty, t = _create_dem_device(xd, yd, zd, cellsize, 'min', None)          # :1741-1742
+    _springs_device(Zmin, "inpaint1")                                               # :1743
+    low_thr = low_filter_slope * (np.array([1]) * cellsize)
+    lib = _lib.load()
+    neg = torch.empty_like(Zmin)
+    _lib.check(lib.smrf_negate_f64(_ptr(Zmin), _ptr(neg), Zmin.numel(), _stream()))
+    low, _ = _progressive_filter_device(neg, np.array([1]), low_thr, False, nan_aware=0)              # :1744
+    del neg
+    if low_outlier_fill:                                                            # :1747-1749
+        _lib.check(lib.smrf_mask_apply_f64(_ptr(Zmin), _ptr(low), None, None, None, Zmin.numel(), _stream()))
+        _springs_device(Zmin, "inpaint1b")
+    thr = slope_threshold * (windows * cellsize)
+    obj, drop = _progressive_filter_device(Zmin, windows, thr, bool(return_extras), nan_aware=0)       # :1752-1755
+    object_cells = torch.empty_like(obj)
+    _lib.check(lib.smrf_mask_apply_f64(_ptr(Zmin), _ptr(empty), _ptr(low), _ptr(obj), _ptr(object_cells),
+                                       Zmin.numel(), _stream()))                    # :1762-1763
+    _springs_device(Zmin, "inpaint2")                                               # :1764
+    Zpro_d = Zmin
+    rows, cols = Zpro_d.shape
+    S_d = torch.empty_like(Zpro_d)
+    _lib.check(lib.smrf_gradient_slope_f64(_ptr(Zpro_d), _ptr(S_d), rows, cols, float(cellsize), _stream()))
+    Zpro = Zpro_d.cpu().numpy()
+    S = S_d.cpu().numpy()
+
+    xh = x if not _is_tensor(x) else x.cpu().numpy()
+    yh = y if not _is_tensor(y) else y.cpu().numpy()
+    zh = z if not _is_tensor(z) else z.cpu().numpy()
+    col_centers = np.arange(0.5, cols + .5)                                         # :1768-1769
+    row_centers = np.arange(0.5, rows + .5)
+    c, r = ~t * (xh, yh)                                                            # :1772
+    elevation_values = interpolate.RectBivariateSpline(row_centers, col_centers, Zpro).ev(r, c)
+    slope_values = interpolate.RectBivariateSpline(row_centers, col_centers, S).ev(r, c)
+    required_value = elevation_threshold + (elevation_scaler * slope_values)        # :1794
+    is_object_point = np.abs(elevation_values - zh) > required_value                # :1795
+    obj_np = object_cells.cpu().numpy().astype(bool)
+    if not return_extras:
+        return Zpro, t, obj_np, is_object_point
+    drop_raster = drop.cpu().numpy()
+    extras = {'above_ground_height': zh - elevation_values, 'drop_raster': drop_raster,
+              'when_dropped': drop_raster[np.round(r).astype(int), np.round(c).astype(int)]}
+    return Zpro, t, obj_np, is_object_point, extras

@@ -1,0 +1,314 @@
+// Disk erosion / dilation entry points, the footprint-gather ("direct") kernel for radii the
+// ring kernels do not cover, and the progressive_filter driver (neilpy.py:1659-1680).
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "smrf_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// direct kernel: one lane per output cell, gathers the whole footprint through L1/L2.
+// O(card(disk)) loads per cell - the fallback for radius > SMRF_RING_MAX_RADIUS and the
+// independent on-device cross-check of the ring kernels in the parity tests.
+// ------------------------------------------------------------------------------------------
+template <typename T, bool DIL>
+__global__ __launch_bounds__(256) void direct_kernel(const DiskArgs<T> a) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = a.out_row0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= a.cols || y >= a.out_row0 + a.out_rows) return;
+  const int r = a.radius;
+  const long long r2 = (long long)r * r;
+  T best = DIL ? -INFINITY : INFINITY;
+  bool first_nan = false;
+  for (int dy = -r; dy <= r; ++dy) {
+    const int ly = smrf_fold(y + dy, a.img_rows) - a.in_row0;
+    const T* row = a.in + (long long)ly * a.ld;
+    long long rem = r2 - (long long)dy * dy;
+    int w = (int)sqrt((double)rem);
+    while ((long long)(w + 1) * (w + 1) <= rem) ++w;
+    while ((long long)w * w > rem) --w;
+    for (int dx = -w; dx <= w; ++dx) {
+      const T v = row[smrf_fold(x + dx, a.cols)];
+      if (dy == -r && dx == 0) first_nan = (v != v);
+      if (DIL) { if (v > best) best = v; } else { if (v < best) best = v; }
+    }
+  }
+  if (a.nan_aware && first_nan) best = DIL ? (T)NAN : (T)NAN;
+  const long long off = (long long)(y - a.out_row0) * a.ld + x;
+  a.out[off] = best;
+  if (a.mask != nullptr) {
+    const T diff = a.last[off] - best;
+    if ((double)diff > a.thr) {
+      a.mask[off] = 1;
+      if (a.when != nullptr) a.when[off] = (uint8_t)a.widx;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void copy_flag_kernel(const DiskArgs<T> a) {   // radius 0
+  const long long n = (long long)a.out_rows * a.cols;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int yy = (int)(i / a.cols), x = (int)(i % a.cols);
+    const T v = a.in[(long long)(a.out_row0 + yy - a.in_row0) * a.ld + x];
+    const long long off = (long long)yy * a.ld + x;
+    a.out[off] = v;
+    if (a.mask != nullptr) {
+      const T diff = a.last[off] - v;
+      if ((double)diff > a.thr) {
+        a.mask[off] = 1;
+        if (a.when != nullptr) a.when[off] = (uint8_t)a.widx;
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void count_nan_kernel(const T* __restrict__ p, long long n,
+                                                        unsigned long long* __restrict__ out) {
+  unsigned long long c = 0;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const T v = p[i];
+    c += (v != v);
+  }
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+template <typename T> struct RingFn;
+template <> struct RingFn<float> {
+  static int call(const DiskArgs<float>& a, bool d, hipStream_t s) {
+    switch (a.radius % SMRF_RING_PARTS) {
+      case 0: return smrf_ring_f32_p0(a, d, s);
+      case 1: return smrf_ring_f32_p1(a, d, s);
+      case 2: return smrf_ring_f32_p2(a, d, s);
+      case 3: return smrf_ring_f32_p3(a, d, s);
+      case 4: return smrf_ring_f32_p4(a, d, s);
+      case 5: return smrf_ring_f32_p5(a, d, s);
+      case 6: return smrf_ring_f32_p6(a, d, s);
+      default: return smrf_ring_f32_p7(a, d, s);
+    }
+  }
+};
+template <> struct RingFn<double> {
+  static int call(const DiskArgs<double>& a, bool d, hipStream_t s) {
+    switch (a.radius % SMRF_RING_PARTS) {
+      case 0: return smrf_ring_f64_p0(a, d, s);
+      case 1: return smrf_ring_f64_p1(a, d, s);
+      case 2: return smrf_ring_f64_p2(a, d, s);
+      case 3: return smrf_ring_f64_p3(a, d, s);
+      case 4: return smrf_ring_f64_p4(a, d, s);
+      case 5: return smrf_ring_f64_p5(a, d, s);
+      case 6: return smrf_ring_f64_p6(a, d, s);
+      default: return smrf_ring_f64_p7(a, d, s);
+    }
+  }
+};
+
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
+// output rows per workgroup for the ring kernels: enough workgroups to fill 256 CUs several
+// times over, but segments long enough that the 2R-row halo each one re-reads stays small
+int pick_seg(int out_rows, int cols, int radius) {
+  const int forced = env_int("SMRF_RING_SEG", 0);
+  if (forced > 0) return forced;
+  const int strips = (cols + 255) / 256;
+  const int target_wgs = env_int("SMRF_RING_WGS", 2048);
+  int nseg = std::max(1, target_wgs / strips);
+  int seg = (out_rows + nseg - 1) / nseg;
+  seg = std::max(seg, std::max(32, 4 * radius));
+  seg = std::min(seg, std::max(out_rows, 1));
+  return ((seg + 3) / 4) * 4;
+}
+
+template <typename T>
+int check_band(const DiskArgs<T>& a) {
+  if (!a.in || !a.out) return smrf_fail(SMRF_E_ARG, "null raster pointer");
+  if (a.img_rows < 1 || a.cols < 1 || a.in_rows < 1 || a.out_rows < 1 || a.radius < 0)
+    return smrf_fail(SMRF_E_ARG, "bad raster size (%d x %d, in %d, out %d, radius %d)", a.img_rows,
+                     a.cols, a.in_rows, a.out_rows, a.radius);
+  if (a.ld < a.cols) return smrf_fail(SMRF_E_ARG, "ld %lld < cols %d", a.ld, a.cols);
+  if (a.out_row0 < 0 || a.out_row0 + a.out_rows > a.img_rows || a.in_row0 < 0 ||
+      a.in_row0 + a.in_rows > a.img_rows)
+    return smrf_fail(SMRF_E_ARG, "row band outside the raster");
+  // every reflected row the outputs need must be inside the input band
+  const int lo = a.out_row0 - a.radius, hi = a.out_row0 + a.out_rows + a.radius;
+  const int span = hi - lo;
+  if (span >= 2 * a.img_rows) {
+    if (a.in_row0 != 0 || a.in_rows != a.img_rows)
+      return smrf_fail(SMRF_E_ARG, "band must hold the whole raster when radius >= rows");
+  } else {
+    for (int y = lo; y < hi; ++y) {
+      const int g = smrf_fold(y, a.img_rows);
+      if (g < a.in_row0 || g >= a.in_row0 + a.in_rows)
+        return smrf_fail(SMRF_E_ARG, "input band [%d,%d) lacks row %d needed by output rows [%d,%d) at radius %d",
+                         a.in_row0, a.in_row0 + a.in_rows, g, a.out_row0, a.out_row0 + a.out_rows, a.radius);
+    }
+  }
+  return SMRF_OK;
+}
+
+template <typename T>
+int disk_filter(DiskArgs<T> a, bool dilate, int impl, hipStream_t stream) {
+  if (int rc = check_band(a)) return rc;
+  if (a.radius == 0) {
+    const long long n = (long long)a.out_rows * a.cols;
+    const int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(copy_flag_kernel<T>, dim3(blocks), dim3(256), 0, stream, a);
+    SMRF_LAUNCH_CHECK();
+    return SMRF_OK;
+  }
+  if (impl == SMRF_IMPL_AUTO) impl = a.radius <= SMRF_RING_MAX_RADIUS ? SMRF_IMPL_RING : SMRF_IMPL_DIRECT;
+  if (impl == SMRF_IMPL_RING) {
+    if (a.radius > SMRF_RING_MAX_RADIUS)
+      return smrf_fail(SMRF_E_UNSUPPORTED, "ring kernels cover radius <= %d (got %d)", SMRF_RING_MAX_RADIUS, a.radius);
+    a.seg = pick_seg(a.out_rows, a.cols, a.radius);
+    return RingFn<T>::call(a, dilate, stream);
+  }
+  if (impl != SMRF_IMPL_DIRECT) return smrf_fail(SMRF_E_ARG, "unknown impl %d", impl);
+  dim3 grid((a.cols + 63) / 64, (a.out_rows + 3) / 4);
+  if (dilate) hipLaunchKernelGGL((direct_kernel<T, true>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((direct_kernel<T, false>), grid, dim3(256), 0, stream, a);
+  SMRF_LAUNCH_CHECK();
+  return SMRF_OK;
+}
+
+template <typename T>
+int disk_filter_api(const T* in, T* out, int img_rows, int cols, int64_t ld, int in_row0, int in_rows,
+                    int out_row0, int out_rows, int radius, int is_dilate, int nan_aware, int impl, void* stream) {
+  DiskArgs<T> a{};
+  a.in = in; a.out = out; a.img_rows = img_rows; a.cols = cols; a.ld = ld;
+  a.in_row0 = in_row0; a.in_rows = in_rows; a.out_row0 = out_row0; a.out_rows = out_rows;
+  a.radius = radius; a.nan_aware = nan_aware;
+  return disk_filter(a, is_dilate != 0, impl, (hipStream_t)stream);
+}
+
+template <typename T>
+int dilate_flag_api(const T* eroded, const T* last, T* opened, uint8_t* mask, uint8_t* when, double thr,
+                    int widx, int img_rows, int cols, int64_t ld, int in_row0, int in_rows, int out_row0,
+                    int out_rows, int radius, int nan_aware, int impl, void* stream) {
+  if (!last || !mask) return smrf_fail(SMRF_E_ARG, "null last/mask pointer");
+  DiskArgs<T> a{};
+  a.in = eroded; a.out = opened; a.last = last; a.mask = mask; a.when = when; a.thr = thr; a.widx = widx;
+  a.img_rows = img_rows; a.cols = cols; a.ld = ld;
+  a.in_row0 = in_row0; a.in_rows = in_rows; a.out_row0 = out_row0; a.out_rows = out_rows;
+  a.radius = radius; a.nan_aware = nan_aware;
+  return disk_filter(a, true, impl, (hipStream_t)stream);
+}
+
+template <typename T>
+int count_nan_api(const T* p, int64_t n, int64_t* h_count, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!h_count || (n > 0 && !p)) return smrf_fail(SMRF_E_ARG, "null pointer");
+  *h_count = 0;
+  if (n <= 0) return SMRF_OK;
+  unsigned long long* d = nullptr;
+  SMRF_HIP_CHECK(hipMallocAsync((void**)&d, sizeof(*d), stream));
+  SMRF_HIP_CHECK(hipMemsetAsync(d, 0, sizeof(*d), stream));
+  const int blocks = (int)std::min<long long>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(count_nan_kernel<T>, dim3(blocks), dim3(256), 0, stream, p, (long long)n, d);
+  unsigned long long h = 0;
+  hipError_t e = hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  hipFreeAsync(d, stream);
+  SMRF_HIP_CHECK(e);
+  *h_count = (int64_t)h;
+  return SMRF_OK;
+}
+
+template <typename T>
+int progressive_filter_api(const T* Z, int rows, int cols, const int32_t* windows, const double* thr, int nwin,
+                           uint8_t* mask, uint8_t* when, void* ws, size_t ws_bytes, int nan_aware, int impl,
+                           void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!Z || !mask || (nwin > 0 && (!windows || !thr))) return smrf_fail(SMRF_E_ARG, "null pointer");
+  if (rows < 1 || cols < 1 || nwin < 0) return smrf_fail(SMRF_E_ARG, "bad size");
+  const size_t need = smrf_progressive_filter_workspace_bytes(rows, cols, (int)sizeof(T));
+  if (ws_bytes < need || !ws) return smrf_fail(SMRF_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, need);
+  for (int i = 0; i < nwin; ++i)
+    if (windows[i] < 0) return smrf_fail(SMRF_E_ARG, "negative window %d", windows[i]);
+  const size_t plane = (size_t)rows * cols;
+  T* E = reinterpret_cast<T*>(ws);
+  T* O[2] = {E + plane, E + 2 * plane};
+  SMRF_HIP_CHECK(hipMemsetAsync(mask, 0, plane, stream));
+  if (when) SMRF_HIP_CHECK(hipMemsetAsync(when, 0, plane, stream));
+  if (nan_aware < 0) {
+    int64_t c = 0;
+    if (int rc = count_nan_api<T>(Z, (int64_t)plane, &c, stream_)) return rc;
+    nan_aware = c > 0;
+  }
+  const T* last = Z;
+  for (int i = 0; i < nwin; ++i) {
+    const int r = windows[i];
+    if (int rc = disk_filter_api<T>(last, E, rows, cols, cols, 0, rows, 0, rows, r, 0, nan_aware, impl, stream_)) return rc;
+    T* opened = O[i & 1];
+    if (int rc = dilate_flag_api<T>(E, last, opened, mask, when, thr[i], i, rows, cols, cols, 0, rows, 0, rows, r,
+                                    nan_aware, impl, stream_))
+      return rc;
+    if (nwin > 1) last = opened;                        // neilpy.py:1675-1676
+  }
+  return SMRF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int smrf_disk_filter_f32(const float* d_in, float* d_out, int img_rows, int cols, int64_t ld, int in_row0,
+                         int in_rows, int out_row0, int out_rows, int radius, int is_dilate, int nan_aware,
+                         int impl, void* stream) {
+  return disk_filter_api<float>(d_in, d_out, img_rows, cols, ld, in_row0, in_rows, out_row0, out_rows, radius,
+                                is_dilate, nan_aware, impl, stream);
+}
+int smrf_disk_filter_f64(const double* d_in, double* d_out, int img_rows, int cols, int64_t ld, int in_row0,
+                         int in_rows, int out_row0, int out_rows, int radius, int is_dilate, int nan_aware,
+                         int impl, void* stream) {
+  return disk_filter_api<double>(d_in, d_out, img_rows, cols, ld, in_row0, in_rows, out_row0, out_rows, radius,
+                                 is_dilate, nan_aware, impl, stream);
+}
+int smrf_pf_dilate_flag_f32(const float* d_eroded, const float* d_last, float* d_opened, uint8_t* d_mask,
+                            uint8_t* d_when_dropped, double threshold, int window_index, int img_rows, int cols,
+                            int64_t ld, int in_row0, int in_rows, int out_row0, int out_rows, int radius,
+                            int nan_aware, int impl, void* stream) {
+  return dilate_flag_api<float>(d_eroded, d_last, d_opened, d_mask, d_when_dropped, threshold, window_index,
+                                img_rows, cols, ld, in_row0, in_rows, out_row0, out_rows, radius, nan_aware, impl,
+                                stream);
+}
+int smrf_pf_dilate_flag_f64(const double* d_eroded, const double* d_last, double* d_opened, uint8_t* d_mask,
+                            uint8_t* d_when_dropped, double threshold, int window_index, int img_rows, int cols,
+                            int64_t ld, int in_row0, int in_rows, int out_row0, int out_rows, int radius,
+                            int nan_aware, int impl, void* stream) {
+  return dilate_flag_api<double>(d_eroded, d_last, d_opened, d_mask, d_when_dropped, threshold, window_index,
+                                 img_rows, cols, ld, in_row0, in_rows, out_row0, out_rows, radius, nan_aware, impl,
+                                 stream);
+}
+size_t smrf_progressive_filter_workspace_bytes(int rows, int cols, int elem_size) {
+  return (size_t)3 * (size_t)rows * (size_t)cols * (size_t)elem_size;
+}
+int smrf_progressive_filter_f32(const float* d_Z, int rows, int cols, const int32_t* h_windows,
+                                const double* h_thresholds, int n_windows, uint8_t* d_mask, uint8_t* d_when_dropped,
+                                void* d_workspace, size_t workspace_bytes, int nan_aware, int impl, void* stream) {
+  return progressive_filter_api<float>(d_Z, rows, cols, h_windows, h_thresholds, n_windows, d_mask, d_when_dropped,
+                                       d_workspace, workspace_bytes, nan_aware, impl, stream);
+}
+int smrf_progressive_filter_f64(const double* d_Z, int rows, int cols, const int32_t* h_windows,
+                                const double* h_thresholds, int n_windows, uint8_t* d_mask, uint8_t* d_when_dropped,
+                                void* d_workspace, size_t workspace_bytes, int nan_aware, int impl, void* stream) {
+  return progressive_filter_api<double>(d_Z, rows, cols, h_windows, h_thresholds, n_windows, d_mask, d_when_dropped,
+                                        d_workspace, workspace_bytes, nan_aware, impl, stream);
+}
+int smrf_count_nan_f32(const float* d_a, int64_t n, int64_t* h_count, void* stream) {
+  return count_nan_api<float>(d_a, n, h_count, stream);
+}
+int smrf_count_nan_f64(const double* d_a, int64_t n, int64_t* h_count, void* stream) {
+  return count_nan_api<double>(d_a, n, h_count, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+// Shared host/device helpers of libsmrf_hip (gfx950 only; no other backend is supported).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "smrf_hip.h"
+
+#define SMRF_HIDDEN __attribute__((visibility("hidden")))
+
+SMRF_HIDDEN int smrf_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define SMRF_HIP_CHECK(expr)                                                                  \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return smrf_fail(SMRF_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),     \
+                       __FILE__, __LINE__);                                                   \
+  } while (0)
+
+#define SMRF_LAUNCH_CHECK() SMRF_HIP_CHECK(hipGetLastError())
+
+// scipy.ndimage mode='reflect' (d c b a | a b c d | d c b a): period 2n fold, any i, n >= 1
+__host__ __device__ inline int smrf_fold(int i, int n) {
+  const int p2 = 2 * n;
+  int p = i % p2;
+  if (p < 0) p += p2;
+  return p < n ? p : p2 - 1 - p;
+}
+
+// integer floor(sqrt(v)), v >= 0
+__host__ __device__ constexpr int smrf_isqrt(int v) {
+  int r = 0;
+  while ((long long)(r + 1) * (r + 1) <= v) ++r;
+  return r;
+}
+
+// arguments of one disk erosion / dilation pass over a row band (see smrf_hip.h)
+template <typename T>
+struct DiskArgs {
+  const T* in;        // first row held = global row in_row0
+  T* out;             // first row = global row out_row0
+  const T* last;      // flag step only (NULL otherwise), first row = out_row0
+  uint8_t* mask;      // flag step only
+  uint8_t* when;      // flag step only, may be NULL
+  double thr;
+  int widx;
+  int img_rows, cols;
+  long long ld;
+  int in_row0, in_rows, out_row0, out_rows;
+  int radius;
+  int nan_aware;
+  int seg;            // output rows per workgroup (ring kernels)
+};
+
+// ring-kernel dispatchers, one per (dtype, radius % SMRF_RING_PARTS); defined in ring_part.hip
+#define SMRF_RING_PARTS 8
+#define SMRF_RING_DECL(P)                                                                     \
+  SMRF_HIDDEN int smrf_ring_f32_p##P(const DiskArgs<float>&, bool dilate, hipStream_t);       \
+  SMRF_HIDDEN int smrf_ring_f64_p##P(const DiskArgs<double>&, bool dilate, hipStream_t);
+SMRF_RING_DECL(0) SMRF_RING_DECL(1) SMRF_RING_DECL(2) SMRF_RING_DECL(3)
+SMRF_RING_DECL(4) SMRF_RING_DECL(5) SMRF_RING_DECL(6) SMRF_RING_DECL(7)
+#undef SMRF_RING_DECL

@@ -1,0 +1,49 @@
+"""The C-ABI library loads and exports every symbol include/smrf_hip.h declares (no GPU needed)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "smrf_hip.h")).read()
+    return sorted(set(re.findall(r"^SMRF_API [\w \*]*?\b(smrf_\w+)\(", text, flags=re.M)))
+
+
+def test_library_exports_every_declared_symbol():
+    from neilpy_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        from neilpy_amd.build import build
+        build(verbose=False)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), "missing export " + n
+    assert sorted(_lib.SIGNATURES) == names, "ctypes SIGNATURES out of sync with smrf_hip.h"
+    assert _lib.load().smrf_abi_version() == 1
+
+
+def test_no_cpu_fallback():
+    """without a GPU the product path raises instead of computing on the host"""
+    import numpy as np
+    import torch
+    import neilpy_amd
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(neilpy_amd.SmrfHipError):
+        neilpy_amd.progressive_filter(np.zeros((8, 8), np.float32), np.array([1, 2]))
+    with pytest.raises(neilpy_amd.SmrfHipError):
+        neilpy_amd.smrf(np.arange(9.0), np.arange(9.0), np.arange(9.0))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "neilpy_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("smrf_oracle.py", "").lower() or f == "build.py", f

@@ -1,0 +1,227 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the reference's goldens.
+
+Bit-exact for masks, when_dropped, opened surfaces and create_dem grids; float64 DTM / inpaint
+within 1e-7 of the reference (north-star tolerance 1e-5) with LSQR's istop/itn equal.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, SAMPLES, golden, load_sample, unpack, zmin_from_centi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nz(gpu_device):
+    import neilpy_amd
+    neilpy_amd.load_library()
+    return neilpy_amd
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import smrf_oracle
+    return smrf_oracle
+
+
+def rand_dem(rng, shape, dtype):
+    base = rng.normal(0, 1, shape).cumsum(0).cumsum(1) * 0.05 + 200
+    spikes = (rng.random(shape) < 0.05) * rng.uniform(1, 25, shape)
+    return (base + spikes).astype(dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("impl", [1, 2])
+def test_disk_filter_vs_oracle(nz, orc, dtype, impl):
+    rng = np.random.default_rng(11)
+    shapes = [(70, 333), (129, 64), (5, 300), (300, 7), (33, 257)]
+    radii = [1, 2, 3, 5, 8, 13, 18, 31, 50, 64]
+    for shape in shapes:
+        Z = rand_dem(rng, shape, dtype)
+        for r in radii:
+            if impl == 2 and r > 18 and shape[0] * shape[1] > 20000:
+                continue
+            fp = orc.disk(r)
+            e = nz.erosion(Z, radius=r, impl=impl)
+            assert e.dtype == dtype
+            assert np.array_equal(e, orc.erosion(Z, fp)), (shape, r, "erosion")
+            d = nz.dilation(Z, radius=r, impl=impl)
+            assert np.array_equal(d, orc.dilation(Z, fp)), (shape, r, "dilation")
+
+
+def test_ring_equals_direct_all_radii(nz):
+    """every ring instantiation (radius 1..64) against the independent direct kernel"""
+    rng = np.random.default_rng(5)
+    for dtype in (np.float32, np.float64):
+        Z = rand_dem(rng, (150, 300), dtype)
+        for r in range(1, 65):
+            for fn in (nz.erosion, nz.dilation):
+                a = fn(Z, radius=r, impl=1)
+                b = fn(Z, radius=r, impl=2)
+                assert np.array_equal(a, b), (dtype, r, fn.__name__)
+
+
+def test_radius_beyond_ring_and_zero(nz, orc):
+    rng = np.random.default_rng(6)
+    Z = rand_dem(rng, (40, 90), np.float32)
+    for r in (0, 65, 100):
+        assert np.array_equal(nz.opening(Z, orc.disk(r)), orc.opening(Z, orc.disk(r)))
+    with pytest.raises(NotImplementedError):
+        nz.opening(Z, np.ones((3, 3), np.uint8))
+
+
+PF = golden("progressive_filter.npz")
+
+
+@pytest.mark.parametrize("impl", [0, 2])
+@pytest.mark.parametrize("tag", [str(c) for c in PF["cases"]])
+def test_progressive_filter_golden(nz, tag, impl):
+    Z = PF[tag + "_Z"]
+    windows = PF[tag + "_windows"]
+    cellsize, slope = PF[tag + "_params"]
+    if cellsize == int(cellsize):
+        cellsize = int(cellsize)
+    Z0 = Z.copy()
+    mask, wd = nz.progressive_filter(Z, windows, cellsize, slope, return_when_dropped=True, impl=impl)
+    assert np.array_equal(Z, Z0, equal_nan=True)
+    assert mask.dtype == bool and wd.dtype == np.uint8
+    assert np.array_equal(mask, unpack(PF[tag + "_mask_bits"], Z.shape))
+    assert np.array_equal(wd, PF[tag + "_when_dropped"])
+    assert np.array_equal(nz.progressive_filter(Z, windows, cellsize, slope, impl=impl), mask)
+    last = Z
+    for w in windows:
+        last = nz.opening(last, nz.disk(int(w)), impl=impl)
+    assert np.array_equal(last, PF[tag + "_opened_last"], equal_nan=True)
+
+
+def test_progressive_filter_torch_in_torch_out(nz, gpu_device):
+    import torch
+    Z = PF["big_f32_w18_Z"]
+    t = torch.from_numpy(Z).to(gpu_device)
+    m = nz.progressive_filter(t, np.arange(1, 19), 1, .15)
+    assert m.is_cuda and m.dtype == torch.bool
+    assert np.array_equal(m.cpu().numpy(), unpack(PF["big_f32_w18_mask_bits"], Z.shape))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_progressive_filter_synth_vs_oracle(nz, orc, dtype):
+    Z = nz.synth_dem(512, seed=20240, dtype=dtype)[:384]
+    windows = np.arange(1, 19)
+    m, w = nz.progressive_filter(Z, windows, 1, .15, return_when_dropped=True)
+    m2, w2 = orc.progressive_filter(Z, windows, 1, .15, return_when_dropped=True)
+    assert np.array_equal(m, m2) and np.array_equal(w, w2)
+
+
+def test_opening_properties_large(nz, gpu_device):
+    """size-independent properties at a size the oracle cannot reach in seconds"""
+    import torch
+    Z = torch.from_numpy(nz.synth_dem(2048, seed=7)).to(gpu_device)
+    for r in (3, 18, 50):
+        o = nz.opening(Z, radius=r)
+        assert bool((o <= Z).all())                           # anti-extensive
+        assert torch.equal(nz.opening(o, radius=r), o)        # idempotent
+        e = nz.erosion(Z, radius=r)
+        assert bool((e <= o).all())
+        if r <= 18:
+            assert torch.equal(nz.erosion(Z, radius=r, impl=2), e)
+
+
+INP = golden("inpaint.npz")
+
+
+@pytest.mark.parametrize("tag", [str(c) for c in INP["cases"]])
+def test_inpaint_golden(nz, tag):
+    A = INP[tag + "_in"]
+    want = INP[tag + "_out"]
+    istop, itn = INP[tag + "_lsqr"]
+    A0 = A.copy()
+    got = nz.inpaint_nans_by_springs(A)
+    assert np.array_equal(A, A0, equal_nan=True)
+    st = nz.last_stats["inpaint"]
+    assert (st["istop"], st["itn"]) == (int(istop), int(itn))
+    assert not np.isnan(got).any()
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-7)
+    known = ~np.isnan(A)
+    assert np.array_equal(got[known], A[known])
+    A2 = A.copy()
+    assert nz.inpaint_nans_by_springs(A2, inplace=True) is None
+    assert np.array_equal(A2, got)
+
+
+CD = golden("create_dem.npz")
+
+
+@pytest.mark.parametrize("tag", [str(c) for c in CD["cases"]])
+def test_create_dem_golden(nz, tag):
+    kw = json.loads(str(CD[tag + "_kwargs_json"]))
+    if kw.get("edges"):
+        kw["edges"] = (CD[tag + "_xedges"], CD[tag + "_yedges"])
+    I, t = nz.create_dem(CD[tag + "_x"], CD[tag + "_y"], CD[tag + "_z"], **kw)
+    want = CD[tag + "_I"]
+    assert I.shape == want.shape and I.dtype == np.float64
+    assert np.array_equal(np.array(tuple(t)[:6]), CD[tag + "_transform"])
+    if kw.get("inpaint"):
+        np.testing.assert_allclose(I, want, rtol=0, atol=1e-7)
+    else:
+        assert np.array_equal(I, want, equal_nan=True)
+
+
+def test_create_dem_errors(nz):
+    with pytest.raises(ValueError, match="This type not supported."):
+        nz.create_dem(np.array([0., 1.]), np.array([0., 1.]), np.array([0., 1.]), bin_type="mean")
+    with pytest.raises(ValueError):
+        nz.create_dem(np.array([1.5, 3.0]), np.array([1.5, 2.5]), np.array([1.0, 2.0]),
+                      edges=(np.arange(0.0, 4.0), np.arange(3.0, -1.0, -1.0)))
+
+
+META = json.load(open(os.path.join(GOLDEN, "meta.json")))
+
+
+def check_smrf(nz, gold, x, y, z, kw, full, stride):
+    Zpro, t, obj, pts, extras = nz.smrf(x, y, z, return_extras=True, **kw)
+    shape = tuple(gold["shape"])
+    assert Zpro.shape == shape and Zpro.dtype == np.float64
+    assert np.array_equal(np.array(tuple(t)[:6]), gold["transform"])
+    st = nz.last_stats
+    assert (st["inpaint1"]["istop"], st["inpaint1"]["itn"]) == tuple(gold["lsqr1"])
+    assert (st["inpaint2"]["istop"], st["inpaint2"]["itn"]) == tuple(gold["lsqr2"])
+    assert obj.dtype == bool and np.array_equal(obj, unpack(gold["object_cells_bits"], shape))
+    assert np.array_equal(extras["drop_raster"], gold["pf_when_dropped"])
+    assert np.array_equal(np.asarray(pts), unpack(gold["is_object_point_bits"], pts.shape))
+    assert np.array_equal(extras["when_dropped"], gold["when_dropped_pts"])
+    if full:
+        np.testing.assert_allclose(Zpro, gold["Zpro"], rtol=0, atol=1e-7)
+    else:
+        np.testing.assert_allclose(Zpro.ravel()[::stride], gold["Zpro_strided"], rtol=0, atol=1e-7)
+    assert abs(float(Zpro.sum()) - float(gold["Zpro_sum"][0])) < 1e-3
+    return pts
+
+
+@pytest.mark.parametrize("name", SAMPLES)
+def test_smrf_samples_golden(nz, name):
+    x, y, z, g = load_sample(name)
+    gold = golden("smrf_%s.npz" % name)
+    pts = check_smrf(nz, gold, x, y, z, META["smrf_kwargs"], name in META["full_dtm"], META["stride"])
+    err = 100.0 * (1.0 - np.mean(pts == g))
+    assert abs(err - META["anchors"][name]["total_error_pct"]) < 1e-9
+
+
+@pytest.mark.parametrize("tag", ["cs0p5", "cs2", "cs0p3", "lowfill", "winlist"])
+def test_smrf_samp11_variants(nz, tag):
+    x, y, z, g = load_sample("samp11")
+    gold = golden("smrf_samp11_%s.npz" % tag)
+    kw = json.loads(str(gold["kwargs_json"]))
+    if isinstance(kw["windows"], list):
+        kw["windows"] = np.array(kw["windows"])
+    check_smrf(nz, gold, x, y, z, kw, False, META["stride"])
+
+
+def test_create_dem_stage_golden_all_samples(nz):
+    for name in SAMPLES:
+        x, y, z, g = load_sample(name)
+        gold = golden("smrf_%s.npz" % name)
+        I, t = nz.create_dem(x, y, z, cellsize=1, bin_type="min")
+        assert np.array_equal(I, zmin_from_centi(gold["Zmin_centi"]), equal_nan=True)
