@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mcells/s through SMRF progressive_filter on a 16384^2 fp32 DEM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 16384] [--windows 50]
+
+A "step" is one full progressive_filter call (all windows: erosion + dilation + flagging per
+window) over the synthetic DEM ``synth_dem(n, seed=20240)`` already resident in HBM.  With N > 1
+(launched by torch.distributed.run, one rank per GPU) the DEM's rows are split into N bands and
+every window exchanges 2r halo rows with the neighbouring ranks over RCCL: the problem size is
+fixed, so ``scaling`` is "strong".  Rank 0 prints ONE JSON line (see README / DESIGN.md).
+
+``roofline``: the ring-kernel launches (2 per window) dominate; ``achieved`` is their
+algorithmic bytes per launch (N*(5*4+2)/2 = 11 B/cell) divided by their average
+duration, measured with events on the launch stream around the timed region.
+``cpu_baseline``: the NumPy/SciPy oracle (the same scipy.ndimage primitive the reference
+reaches through skimage), single thread, on a bounded crop of the same DEM with the same windows.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=16384, help="DEM is n x n cells")
+    ap.add_argument("--windows", type=int, default=50, help="radii 1..windows")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--cpu-crop", type=int, default=192, help="crop edge for the CPU baseline (0 = skip)")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(Z_crop, windows, cellsize, slope):
+    """The oracle timed on the host: single process, single thread (how the reference runs)."""
+    from oracle import smrf_oracle as orc
+    t0 = time.perf_counter()
+    orc.progressive_filter(Z_crop, windows, cellsize, slope)
+    dt = time.perf_counter() - t0
+    return dict(value=Z_crop.size / dt / 1e6, unit="Mcells/s", cores=1, kind="port", seconds=round(dt, 3),
+                sample="oracle/smrf_oracle.py progressive_filter (scipy.ndimage grey_erosion/grey_dilation, "
+                       "disk footprints, 1 thread) on the %dx%d top-left crop of the same DEM, windows 1..%d"
+                       % (Z_crop.shape[0], Z_crop.shape[1], len(windows)))
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    import neilpy_amd
+    from neilpy_amd import api, sharded
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (a.gpus, a.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: neilpy_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = a.n
+    np_dtype = np.float32 if a.dtype == "f32" else np.float64
+    windows = np.arange(1, a.windows + 1)
+    cellsize, slope = 1, .15
+    thresholds = slope * (windows * cellsize)
+    b0, b1 = sharded.band_rows(n, world, rank)
+    Z_host = neilpy_amd.synth_dem(n, seed=20240, dtype=np_dtype, row_range=(b0, b1))
+    Z = torch.from_numpy(Z_host).to(dev)
+    crop = None
+    if rank == 0 and not a.no_cpu and a.cpu_crop > 0:
+        c = min(a.cpu_crop, n, b1 - b0)
+        crop = np.ascontiguousarray(Z_host[:c, :c])
+    del Z_host
+
+    state = {}
+
+    def step():
+        if world == 1:
+            return api._progressive_filter_device(Z, windows, thresholds, False, nan_aware=0)[0]
+        return sharded.progressive_filter_sharded(Z, n, windows, thresholds, rank=rank, world_size=world, state=state)[0]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        mask = step()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(a.steps):
+        mask = step()
+    ev1.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)                       # kernels of this rank's stream only
+    n_obj = int(mask.sum().item())
+    if world > 1:
+        t = torch.tensor([dt, dev_ms, float(n_obj)], dtype=torch.float64, device=dev)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt, dev_ms, n_obj = float(tmax[0]), float(tmax[1]), int(t[2])
+
+    if rank == 0:
+        cells = n * n
+        elem = 4 if a.dtype == "f32" else 8
+        ms_per_step = dt / a.steps * 1e3
+        launches = 2 * len(windows)                              # erosion + dilation/flag per window
+        alg_bytes_launch = cells / world * (5 * elem + 2) / 2.0  # per rank, per launch
+        avg_launch_s = dev_ms / 1e3 / a.steps / launches
+        achieved = alg_bytes_launch / avg_launch_s / 1e9
+        peak = 8000.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                if rec.get("n") == n and rec.get("windows") == a.windows and rec.get("dtype") == a.dtype and world == 1:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                traffic = None
+        out = {
+            "metric": "Mcells/s through SMRF progressive_filter, %dx%d %s DEM" % (n, n, "fp32" if elem == 4 else "fp64"),
+            "value": cells / (dt / a.steps) / 1e6, "unit": "Mcells/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": "progressive_filter %dx%d %s, windows 1..%d, cellsize 1, slope_threshold 0.15, "
+                                   "synth_dem(seed=20240)" % (n, n, "fp32" if elem == 4 else "fp64", a.windows),
+                       "sharding": "row bands x%d, 2r-row halo exchange per window (RCCL send/recv)" % world
+                       if world > 1 else "single device", "object_cells": n_obj},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+                         "traffic": traffic, "kernel": "smrf::ring_kernel (all radii; %d launches per step)" % launches,
+                         "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": avg_launch_s * 1e3},
+        }
+        if crop is not None:
+            out["cpu_baseline"] = cpu_baseline(crop, windows, cellsize, slope)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,12 +1,16 @@
-"""Seeded synthetic inputs for the SMRF hot path (SURVEY.md §8d).
+"""Seeded synthetic inputs for the SMRF hot path (SURVEY.md section 8d).
 
-The generators use ``numpy.random.default_rng`` (PCG64), so the same seed gives
-the same array on any host.  They are used by ``bench.py``, by the parity tests
-and by ``tests/golden/make_golden.py``; nothing here touches the GPU.
+The generators use ``numpy.random`` PCG64 streams, so the same seed gives the same array on any
+host.  ``synth_dem`` draws its random fields per 256-row block from a stream keyed by
+``(seed, block)``: any row band of a large DEM can be generated on its own (each rank of a
+sharded run builds only its rows) and equals the corresponding rows of the full DEM.
+Used by ``bench.py``, the parity tests and ``tests/golden/make_golden.py``; no GPU involved.
 """
 import numpy as np
 
 __all__ = ["synth_dem", "synth_points", "terrain"]
+
+_BLOCK = 256
 
 
 def terrain(xx, yy):
@@ -15,41 +19,41 @@ def terrain(xx, yy):
             + 0.01 * xx + 0.005 * yy + 300.0)
 
 
-def synth_dem(n, seed=20240, dtype=np.float32, rows=None):
-    """``rows x n`` DEM: terrain + boxes ("buildings") + salt ("vegetation") + noise.
-
-    ``rows`` defaults to ``n``.  Memory is bounded by generating in row strips
-    for the random fields, but the box list is drawn first so that a ``rows``
-    crop of a larger DEM is *not* the same as a smaller DEM - callers that need
-    a crop should generate the full DEM and slice it.
-    """
+def synth_dem(n, seed=20240, dtype=np.float32, rows=None, row_range=None):
+    """``rows x n`` DEM (``rows`` defaults to ``n``): terrain + boxes ("buildings", ``rows*n/8192``
+    of them, half-sizes 3..39 cells, 3..30 m high) + 3 % salt ("vegetation", 1..20 m) + N(0, 0.03)
+    noise.  ``row_range=(r0, r1)`` returns only those rows of the same DEM."""
     m = n if rows is None else int(rows)
-    rng = np.random.default_rng(seed)
+    r0, r1 = (0, m) if row_range is None else (int(row_range[0]), int(row_range[1]))
+    rng = np.random.default_rng([seed, 0xB0C5])
     k = max(1, (m * n) // 8192)
     cy = rng.integers(0, m, size=k)
     cx = rng.integers(0, n, size=k)
     hy = rng.integers(3, 40, size=k)
     hx = rng.integers(3, 40, size=k)
     hh = rng.uniform(3.0, 30.0, size=k)
-    out = np.empty((m, n), dtype=np.float64)
-    strip = max(1, min(m, (1 << 24) // max(n, 1)))
     xs = np.arange(n, dtype=np.float64)[None, :]
-    for r0 in range(0, m, strip):
-        r1 = min(m, r0 + strip)
-        ys = np.arange(r0, r1, dtype=np.float64)[:, None]
-        out[r0:r1] = terrain(xs, ys)
-    base = out.copy() if k else out
-    for i in range(k):
-        y0, y1 = max(0, cy[i] - hy[i]), min(m, cy[i] + hy[i] + 1)
+    ys = np.arange(r0, r1, dtype=np.float64)[:, None]
+    base = terrain(xs, ys)
+    out = base.copy()
+    sel = np.flatnonzero((cy + hy >= r0) & (cy - hy < r1))
+    for i in sel:
+        y0, y1 = max(r0, cy[i] - hy[i]), min(r1, cy[i] + hy[i] + 1)
         x0, x1 = max(0, cx[i] - hx[i]), min(n, cx[i] + hx[i] + 1)
-        np.maximum(out[y0:y1, x0:x1], base[y0:y1, x0:x1] + hh[i], out=out[y0:y1, x0:x1])
+        if y0 >= y1:
+            continue
+        np.maximum(out[y0 - r0:y1 - r0, x0:x1], base[y0 - r0:y1 - r0, x0:x1] + hh[i],
+                   out=out[y0 - r0:y1 - r0, x0:x1])
     del base
-    for r0 in range(0, m, strip):
-        r1 = min(m, r0 + strip)
-        veg = rng.random((r1 - r0, n)) < 0.03
-        vh = rng.uniform(1.0, 20.0, size=(r1 - r0, n))
-        out[r0:r1] += veg * vh
-        out[r0:r1] += rng.normal(0.0, 0.03, size=(r1 - r0, n))
+    for blk in range(r0 // _BLOCK, (r1 + _BLOCK - 1) // _BLOCK):
+        brng = np.random.default_rng([seed, 0xF1E1D, blk])
+        b0, b1 = blk * _BLOCK, min(m, (blk + 1) * _BLOCK)
+        veg = brng.random((b1 - b0, n)) < 0.03
+        vh = brng.uniform(1.0, 20.0, size=(b1 - b0, n))
+        noise = brng.normal(0.0, 0.03, size=(b1 - b0, n))
+        field = veg * vh + noise
+        lo, hi = max(b0, r0), min(b1, r1)
+        out[lo - r0:hi - r0] += field[lo - b0:hi - b0]
     return out.astype(dtype)
 
 

@@ -44,6 +44,13 @@ def test_disk_filter_vs_oracle(nz, orc, dtype, impl):
         for r in radii:
             if impl == 2 and r > 18 and shape[0] * shape[1] > 20000:
                 continue
+            if r >= 4 * min(shape):
+                # scipy's reflect offsets go out of bounds there (NI_InitFilterOffsets maps offsets
+                # that are a multiple of 2*len below -2*len to index -1): the reference's result is
+                # uninitialised memory, nothing to compare with.  Covered by ring-vs-direct below.
+                a, b = nz.erosion(Z, radius=r, impl=1), nz.erosion(Z, radius=r, impl=2)
+                assert np.array_equal(a, b), (shape, r)
+                continue
             fp = orc.disk(r)
             e = nz.erosion(Z, radius=r, impl=impl)
             assert e.dtype == dtype
