@@ -109,25 +109,6 @@ template <> struct RingFn<double> {
   }
 };
 
-int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v && *v ? atoi(v) : dflt;
-}
-
-// output rows per workgroup for the ring kernels: enough workgroups to fill 256 CUs several
-// times over, but segments long enough that the 2R-row halo each one re-reads stays small
-int pick_seg(int out_rows, int cols, int radius) {
-  const int forced = env_int("SMRF_RING_SEG", 0);
-  if (forced > 0) return forced;
-  const int strips = (cols + 255) / 256;
-  const int target_wgs = env_int("SMRF_RING_WGS", 2048);
-  int nseg = std::max(1, target_wgs / strips);
-  int seg = (out_rows + nseg - 1) / nseg;
-  seg = std::max(seg, std::max(32, 4 * radius));
-  seg = std::min(seg, std::max(out_rows, 1));
-  return ((seg + 3) / 4) * 4;
-}
-
 template <typename T>
 int check_band(const DiskArgs<T>& a) {
   if (!a.in || !a.out) return smrf_fail(SMRF_E_ARG, "null raster pointer");
@@ -169,7 +150,7 @@ int disk_filter(DiskArgs<T> a, bool dilate, int impl, hipStream_t stream) {
   if (impl == SMRF_IMPL_RING) {
     if (a.radius > SMRF_RING_MAX_RADIUS)
       return smrf_fail(SMRF_E_UNSUPPORTED, "ring kernels cover radius <= %d (got %d)", SMRF_RING_MAX_RADIUS, a.radius);
-    a.seg = pick_seg(a.out_rows, a.cols, a.radius);
+    a.seg = smrf_env_int("SMRF_RING_SEG", 0);   // 0: the launcher sizes segments from its occupancy
     return RingFn<T>::call(a, dilate, stream);
   }
   if (impl != SMRF_IMPL_DIRECT) return smrf_fail(SMRF_E_ARG, "unknown impl %d", impl);

@@ -19,9 +19,16 @@
 // written out (coalesced).  No MFMA: there is no contraction in this computation; the kernel is
 // bound by LDS reads + VALU min/max, HBM traffic is ~2 plane passes.
 #pragma once
+#include <algorithm>
 #include <utility>
 
 #include "smrf_common.h"
+
+#ifndef SMRF_FORCE_OCC
+#define SMRF_OCC_OVERRIDE(...) __VA_ARGS__
+#else
+#define SMRF_OCC_OVERRIDE(...) SMRF_FORCE_OCC
+#endif
 
 namespace smrf {
 
@@ -56,15 +63,15 @@ template <bool DIL>
 __device__ __forceinline__ float op2(float a, float b) {
   float r;
   // single instruction, no canonicalising v_max in front (IEEE minNum/maxNum: a NaN operand loses)
-  if constexpr (DIL) asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  else asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  if constexpr (DIL) asm volatile("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  else asm volatile("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
 template <bool DIL>
 __device__ __forceinline__ double op2(double a, double b) {
   double r;
-  if constexpr (DIL) asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  else asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  if constexpr (DIL) asm volatile("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  else asm volatile("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
 
@@ -76,133 +83,114 @@ template <typename T> __device__ __forceinline__ T qnan();
 template <> __device__ __forceinline__ float qnan<float>() { return __builtin_nanf(""); }
 template <> __device__ __forceinline__ double qnan<double>() { return __builtin_nan(""); }
 
-template <typename T, int R, int TW, int B>
+template <typename T> struct Vec2;
+template <> struct Vec2<float> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct Vec2<double> { typedef double type __attribute__((ext_vector_type(2))); };
+
+template <bool DIL>
+__device__ __forceinline__ float op3(float a, float b, float c) {
+  float r;
+  if constexpr (DIL) asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  else asm volatile("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+template <bool DIL>
+__device__ __forceinline__ double op3(double a, double b, double c) { return op2<DIL>(op2<DIL>(a, b), c); }
+
+// Geometry of one kernel instance.  Input rows are handled in PAIRS (A = y, B = y+1): the two
+// rows are interleaved cell by cell in LDS ({A, B} per cell), so one ds_read_b64 serves a window
+// lookup of both rows and one v_min3 folds both rows into a ring slot.
+template <typename T, int R, int TW, int NP>
 struct RingCfg {
   using S = DiskShape<R>;
-  static constexpr int W = TW + 2 * R;                 // staged cells per row
-  static constexpr int PAD = 1 << (S::J > 0 ? S::J - 1 : 0);
-  static constexpr int WP = ((W + PAD + 3) / 4) * 4;   // row pitch of one table level
-  static constexpr int ROWP = (S::J + 1) * WP;         // cells per staged row (all levels)
-  static constexpr size_t LDS_BYTES = (size_t)(B * ROWP + PAD) * sizeof(T);
   static constexpr int E = sizeof(T) / 4;
-  static constexpr int NEED = E * ((2 * R + 1) + S::K + 4 * B + 8) + 28;   // VGPR estimate
-  static constexpr int OCC = NEED <= 64 ? 8 : NEED <= 96 ? 5 : NEED <= 128 ? 4 : NEED <= 168 ? 3 : NEED <= 256 ? 2 : 1;
+  static constexpr int W = TW + 2 * R;                   // staged cells per row
+  static constexpr int PAD = 1 << (S::J > 0 ? S::J - 1 : 0);
+  static constexpr int WP = ((W + PAD + 3) / 4) * 4;     // pitch of one table level (cells)
+  static constexpr int ROWS = 2 * NP;                    // input rows per batch
+  static constexpr size_t LDS_BYTES = ((size_t)NP * (S::J + 1) * WP + PAD) * 2 * sizeof(T);
+  static constexpr int G = 4;                            // window lookups per pipelined group
+  static constexpr int NG = (S::K - 1 + G - 1) / G;      // groups for k = 1..K-1
+  static constexpr int NEED = E * (2 * R + 2 * S::K + 36) + 16;   // measured VGPR demand
+  static constexpr int OCC_REG = NEED <= 64 ? 8 : NEED <= 96 ? 5 : NEED <= 128 ? 4 : NEED <= 168 ? 3 : NEED <= 256 ? 2 : 1;
+  static constexpr int OCC_LDS = (int)(160 * 1024 / LDS_BYTES) < 1 ? 1 : (int)(160 * 1024 / LDS_BYTES);
+  static constexpr int OCC = OCC_REG < OCC_LDS ? OCC_REG : OCC_LDS;   // workgroups (= waves/SIMD) per CU
+  // ring slot s (0 .. 2R-3) after a pair takes min3(acc[s+2], RA[kA(s)], RB[kB(s)])
+  static constexpr int kA(int s) { int d = R - s - 2; return S::kidx(d < 0 ? -d : d); }
+  static constexpr int kB(int s) { int d = R - s - 1; return S::kidx(d < 0 ? -d : d); }
+  // lookup group after which slot s can be updated (first half: as soon as its widths are there;
+  // second half: after the last group).  Group g covers k in [1 + g*G, 1 + (g+1)*G).
+  static constexpr int slot_group(int s) {
+    if (s > R - 2) return NG;                            // second half (and the middle): at the end
+    const int k = kA(s);                                 // kA >= kB in the first half
+    return k == 0 ? 0 : (k - 1) / G;
+  }
 };
 
-template <typename T, int R, bool DIL, int TW, int B>
-__global__ __launch_bounds__(TW, (RingCfg<T, R, TW, B>::OCC))
+template <typename T, int R, bool DIL, int TW, int NP>
+__global__ __launch_bounds__(TW, (SMRF_OCC_OVERRIDE(RingCfg<T, R, TW, NP>::OCC)))
 void ring_kernel(const DiskArgs<T> a) {
-  using C = RingCfg<T, R, TW, B>;
+  using C = RingCfg<T, R, TW, NP>;
   using S = typename C::S;
-  constexpr int J = S::J, K = S::K, WP = C::WP, ROWP = C::ROWP;
+  using T2 = typename Vec2<T>::type;
+  constexpr int J = S::J, K = S::K, WP = C::WP, G = C::G, NG = C::NG, ROWS = C::ROWS;
+  constexpr int KR1 = S::kidx(R - 1);                   // width index of dy = +-(R-1)
   extern __shared__ __attribute__((aligned(16))) unsigned char smrf_lds[];
-  T* const L = reinterpret_cast<T*>(smrf_lds);          // [B][J+1][WP]
+  T2* const L = reinterpret_cast<T2*>(smrf_lds);         // [NP][J+1][WP] of {row A, row B}
 
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x * TW;
   const int x = x0 + tid;
-  const int ys = a.out_row0 + blockIdx.y * a.seg;                       // global output rows [ys, ye)
+  const int ys = a.out_row0 + blockIdx.y * a.seg;        // global output rows [ys, ye)
   const int ye = min(a.out_row0 + a.out_rows, ys + a.seg);
   const bool has2 = tid < 2 * R;
   const int c0 = smrf_fold(x0 - R + tid, a.cols);
-  const int c1 = has2 ? smrf_fold(x0 - R + tid + TW, a.cols) : 0;
+  const int c1 = has2 ? smrf_fold(x0 - R + tid + TW, a.cols) : c0;
   const int last_in = a.in_rows - 1;
+  const bool flag = a.mask != nullptr;
+  const int xc = x < a.cols ? x : a.cols - 1;
 
-  T acc[2 * R + 1];
+  // ring: between pairs, slot s holds the partial result of output row (next input row) - R + s
+  T acc[2 * R];
 #pragma unroll
-  for (int i = 0; i <= 2 * R; ++i) acc[i] = ident<T>(DIL);
+  for (int i = 0; i < 2 * R; ++i) acc[i] = ident<T>(DIL);
 
-  T pf0[B], pf1[B];
+  T2 pf0[NP], pf1[NP];                                   // next batch, cells tid and tid + TW
+  T outv[ROWS], lastv[ROWS];
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) { outv[i] = T(0); lastv[i] = T(0); }
+
   auto prefetch = [&](int yy0) {
 #pragma unroll
-    for (int b = 0; b < B; ++b) {
-      int ly = smrf_fold(yy0 + b, a.img_rows) - a.in_row0;
-      ly = ly < 0 ? 0 : (ly > last_in ? last_in : ly);   // only rows past the segment's halo clamp
-      const T* row = a.in + (long long)ly * a.ld;
-      pf0[b] = row[c0];
-      pf1[b] = has2 ? row[c1] : T(0);
+    for (int p = 0; p < NP; ++p) {
+      int la = smrf_fold(yy0 + 2 * p, a.img_rows) - a.in_row0;
+      int lb = smrf_fold(yy0 + 2 * p + 1, a.img_rows) - a.in_row0;
+      la = la < 0 ? 0 : (la > last_in ? last_in : la);   // only rows past the segment's halo clamp
+      lb = lb < 0 ? 0 : (lb > last_in ? last_in : lb);
+      const T* ra = a.in + (long long)la * a.ld;
+      const T* rb = a.in + (long long)lb * a.ld;
+      pf0[p].x = ra[c0]; pf0[p].y = rb[c0];
+      pf1[p].x = ra[c1]; pf1[p].y = rb[c1];
     }
   };
-  prefetch(ys - R);
-
-  for (int yy0 = ys - R; yy0 < ye + R; yy0 += B) {
-    T v0[B], v1[B];
+  // outputs of the batch whose first input row was yyb; written one iteration late so that no
+  // store is younger than the prefetch loads the loop waits for
+  auto epilogue = [&](int yyb) {
 #pragma unroll
-    for (int b = 0; b < B; ++b) {
-      v0[b] = pf0[b];
-      v1[b] = pf1[b];
-      L[b * ROWP + tid] = v0[b];
-      if (has2) L[b * ROWP + tid + TW] = v1[b];
-    }
-    __syncthreads();
-    if (yy0 + B < ye + R) prefetch(yy0 + B);            // next batch, consumed next iteration
-#pragma unroll
-    for (int j = 1; j <= J; ++j) {
-      const int h = 1 << (j - 1);
-#pragma unroll
-      for (int b = 0; b < B; ++b) {
-        const T* Lm = L + b * ROWP + (j - 1) * WP;
-        T* Lj = L + b * ROWP + j * WP;
-        v0[b] = op2<DIL>(v0[b], Lm[tid + h]);
-        Lj[tid] = v0[b];
-        if (has2) {
-          v1[b] = op2<DIL>(v1[b], Lm[tid + TW + h]);
-          Lj[tid + TW] = v1[b];
-        }
-      }
-      __syncthreads();
-    }
-
-#pragma unroll 1
-    for (int b = 0; b < B; ++b) {
-      const T* q = L + b * ROWP + tid + R;               // this lane's cell in level 0
-      T rv[K];
-      rv[0] = q[0];
-      // window minima for the K distinct half-widths, 8 lookups per group: loads first, then mins
-      [&]<int... G>(std::integer_sequence<int, G...>) {
-        (([&] {
-           constexpr int k0 = 1 + 8 * G;
-           constexpr int n = (K - k0) < 8 ? (K - k0) : 8;
-           T ta[8], tb[8];
-           [&]<int... I>(std::integer_sequence<int, I...>) {
-             (([&] {
-                constexpr int w = S::wk(k0 + I);
-                constexpr int j = clog2(2 * w + 1);
-                ta[I] = q[j * WP - w];
-                tb[I] = q[j * WP + w - (1 << j) + 1];
-              }()), ...);
-           }(std::make_integer_sequence<int, n>{});
-           __builtin_amdgcn_sched_barrier(0);
-           [&]<int... I>(std::integer_sequence<int, I...>) {
-             ((rv[k0 + I] = op2<DIL>(ta[I], tb[I])), ...);
-           }(std::make_integer_sequence<int, n>{});
-           __builtin_amdgcn_sched_barrier(0);
-         }()), ...);
-      }(std::make_integer_sequence<int, (K - 1 + 7) / 8>{});
-
-      // ring update: slot s <- slot s+1 combined with this row's window for dy = R - s
-      [&]<int... Sl>(std::integer_sequence<int, Sl...>) {
-        (([&] {
-           constexpr int dy = R - Sl;
-           constexpr int k = S::kidx(dy < 0 ? -dy : dy);
-           acc[Sl] = op2<DIL>(acc[Sl + 1], rv[k]);
-         }()), ...);
-      }(std::make_integer_sequence<int, 2 * R>{});
-      acc[2 * R] = rv[0];
-
-      const int yo = yy0 + b - R;                         // output row completed by this input row
+    for (int i = 0; i < ROWS; ++i) {
+      const int yo = yyb + i - R;
       if (yo >= ys && yo < ye && x < a.cols) {
-        T val = acc[0];
+        T val = outv[i];
         const long long off = (long long)(yo - a.out_row0) * a.ld + x;
         if (a.nan_aware) {
           // scipy: the first visited footprint element (offset (-R, 0)) decides NaN-ness
-          int ly = smrf_fold(yo - R, a.img_rows) - a.in_row0;
+          const int ly = smrf_fold(yo - R, a.img_rows) - a.in_row0;
           const T first = a.in[(long long)ly * a.ld + x];
           if (first != first) val = qnan<T>();
         }
         a.out[off] = val;
-        if (a.mask != nullptr) {
-          const T diff = a.last[off] - val;               // raster dtype
+        if (flag) {
+          const T diff = lastv[i] - val;                  // raster dtype
           if ((double)diff > a.thr) {                     // float64 comparison (NumPy 2)
             a.mask[off] = 1;
             if (a.when != nullptr) a.when[off] = (uint8_t)a.widx;
@@ -210,16 +198,131 @@ void ring_kernel(const DiskArgs<T> a) {
         }
       }
     }
+  };
+  auto load_last = [&](int yyb) {
+    if (!flag) return;
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      int yo = yyb + i - R - a.out_row0;
+      yo = yo < 0 ? 0 : (yo >= a.out_rows ? a.out_rows - 1 : yo);
+      lastv[i] = a.last[(long long)yo * a.ld + xc];
+    }
+  };
+
+  prefetch(ys - R);
+  for (int yy0 = ys - R; yy0 < ye + R; yy0 += ROWS) {
+    T2 v0[NP], v1[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      v0[p] = pf0[p];
+      v1[p] = pf1[p];
+      L[p * (J + 1) * WP + tid] = v0[p];
+      if (has2) L[p * (J + 1) * WP + tid + TW] = v1[p];
+    }
     __syncthreads();
+    if (yy0 > ys - R) epilogue(yy0 - ROWS);
+    if (yy0 + ROWS < ye + R) prefetch(yy0 + ROWS);
+    load_last(yy0);
+
+    // per-row sparse tables: level j holds the min/max over 2^j cells starting at the cell
+#pragma unroll
+    for (int j = 1; j <= J; ++j) {
+      const int h = 1 << (j - 1);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const T2* Lm = L + (p * (J + 1) + j - 1) * WP;
+        T2* Lj = L + (p * (J + 1) + j) * WP;
+        const T2 n0 = Lm[tid + h];
+        v0[p].x = op2<DIL>(v0[p].x, n0.x); v0[p].y = op2<DIL>(v0[p].y, n0.y);
+        Lj[tid] = v0[p];
+        if (has2) {
+          const T2 n1 = Lm[tid + TW + h];
+          v1[p].x = op2<DIL>(v1[p].x, n1.x); v1[p].y = op2<DIL>(v1[p].y, n1.y);
+          Lj[tid + TW] = v1[p];
+        }
+      }
+      __syncthreads();
+    }
+
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const T2* q = L + p * (J + 1) * WP + tid + R;        // this lane's cell, level 0
+      T ra[K], rb[K];                                      // window results of row A / row B per width
+      T2 ta[2][G], tb[2][G];
+      auto issue = [&]<int GI>(std::integral_constant<int, GI>) {
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+          (([&] {
+             constexpr int k = 1 + GI * G + I;
+             if constexpr (k < K) {
+               constexpr int w = S::wk(k);
+               constexpr int j = clog2(2 * w + 1);
+               ta[GI & 1][I] = q[j * WP - w];
+               tb[GI & 1][I] = q[j * WP + w - (1 << j) + 1];
+             }
+           }()), ...);
+        }(std::make_integer_sequence<int, G>{});
+      };
+      auto reduce = [&]<int GI>(std::integral_constant<int, GI>) {
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+          (([&] {
+             constexpr int k = 1 + GI * G + I;
+             if constexpr (k < K) {
+               ra[k] = op2<DIL>(ta[GI & 1][I].x, tb[GI & 1][I].x);
+               rb[k] = op2<DIL>(ta[GI & 1][I].y, tb[GI & 1][I].y);
+             }
+           }()), ...);
+        }(std::make_integer_sequence<int, G>{});
+      };
+      auto slots = [&]<int GI>(std::integral_constant<int, GI>) {   // ring slots released by group GI
+        [&]<int... Sl>(std::integer_sequence<int, Sl...>) {
+          (([&] {
+             if constexpr (C::slot_group(Sl) == GI) {
+               constexpr int ka = C::kA(Sl), kb = C::kB(Sl);   // forced compile-time: static registers
+               acc[Sl] = op3<DIL>(acc[Sl + 2], ra[ka], rb[kb]);
+             }
+           }()), ...);
+        }(std::make_integer_sequence<int, (2 * R - 2 > 0 ? 2 * R - 2 : 0)>{});
+      };
+
+      const T2 c = q[0];
+      ra[0] = c.x;
+      rb[0] = c.y;
+      if constexpr (NG > 0) issue(std::integral_constant<int, 0>{});
+      // the two rows this pair completes (before their slots are overwritten)
+      outv[2 * p] = op2<DIL>(acc[0], ra[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      [&]<int... GI>(std::integer_sequence<int, GI...>) {
+        (([&] {
+           if constexpr (GI + 1 < NG) issue(std::integral_constant<int, GI + 1>{});
+           __builtin_amdgcn_sched_barrier(0);
+           reduce(std::integral_constant<int, GI>{});
+           if constexpr (GI == 0) {
+             if constexpr (R >= 2) outv[2 * p + 1] = op3<DIL>(acc[1], ra[KR1], rb[0]);
+           }
+           slots(std::integral_constant<int, GI>{});
+           __builtin_amdgcn_sched_barrier(0);
+         }()), ...);
+      }(std::make_integer_sequence<int, NG>{});
+      if constexpr (R == 1) outv[2 * p + 1] = op3<DIL>(acc[1], ra[KR1], rb[0]);
+      slots(std::integral_constant<int, NG>{});           // second half, all widths are in registers
+      acc[2 * R - 2] = op2<DIL>(ra[0], rb[KR1]);
+      acc[2 * R - 1] = rb[0];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+  {
+    const int nb = (ye + R - (ys - R) + ROWS - 1) / ROWS;
+    epilogue(ys - R + (nb - 1) * ROWS);
   }
 }
 
 template <typename T, int R, bool DIL>
-int ring_launch(const DiskArgs<T>& a, hipStream_t stream) {
+int ring_launch(const DiskArgs<T>& a_in, hipStream_t stream) {
   constexpr int TW = 256;
-  constexpr int B = sizeof(T) == 4 ? 4 : 2;
-  using C = RingCfg<T, R, TW, B>;
-  auto kern = ring_kernel<T, R, DIL, TW, B>;
+  constexpr int NP = sizeof(T) == 4 ? 2 : 1;
+  using C = RingCfg<T, R, TW, NP>;
+  auto kern = ring_kernel<T, R, DIL, TW, NP>;
   static bool attr_done = false;
   if (!attr_done) {
     if (C::LDS_BYTES > 48 * 1024)
@@ -227,7 +330,20 @@ int ring_launch(const DiskArgs<T>& a, hipStream_t stream) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
     attr_done = true;
   }
-  dim3 grid((a.cols + TW - 1) / TW, (a.out_rows + a.seg - 1) / a.seg);
+  DiskArgs<T> a = a_in;
+  const int strips = (a.cols + TW - 1) / TW;
+  if (a.seg <= 0) {
+    // output rows per workgroup: about `rounds` full waves of resident workgroups (OCC per CU on
+    // 256 CUs), but segments long enough that the 2R halo rows each one re-reads stay a small part
+    const int rounds = smrf_env_int("SMRF_RING_ROUNDS", 2);
+    const int nseg = std::max(1, (rounds * C::OCC * 256 + strips / 2) / strips);
+    int seg = (a.out_rows + nseg - 1) / nseg;
+    seg = std::max(seg, std::max(32, 4 * R));
+    seg = std::min(seg, a.out_rows);
+    a.seg = seg;
+  }
+  a.seg = ((a.seg + C::ROWS - 1) / C::ROWS) * C::ROWS;
+  dim3 grid(strips, (a.out_rows + a.seg - 1) / a.seg);
   hipLaunchKernelGGL(kern, grid, dim3(TW), C::LDS_BYTES, stream, a);
   SMRF_LAUNCH_CHECK();
   return SMRF_OK;

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "smrf_hip.h"
 
@@ -27,6 +28,11 @@ __host__ __device__ inline int smrf_fold(int i, int n) {
   int p = i % p2;
   if (p < 0) p += p2;
   return p < n ? p : p2 - 1 - p;
+}
+
+inline int smrf_env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
 }
 
 // integer floor(sqrt(v)), v >= 0
