@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--cpu-crop", type=int, default=192, help="crop edge for the CPU baseline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo stages halos through the host: for rehearsing N>1 ranks on one GPU")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal on a one-GPU box)")
     return ap.parse_args()
 
 
@@ -66,11 +69,16 @@ def main():
         raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (a.gpus, a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: neilpy_amd has no CPU fallback")
+    if a.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     n = a.n
     np_dtype = np.float32 if a.dtype == "f32" else np.float64
@@ -113,7 +121,7 @@ def main():
     dev_ms = ev0.elapsed_time(ev1)                       # kernels of this rank's stream only
     n_obj = int(mask.sum().item())
     if world > 1:
-        t = torch.tensor([dt, dev_ms, float(n_obj)], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, dev_ms, float(n_obj)], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

@@ -64,17 +64,33 @@ class HipBandOps:
 
 
 def _exchange(dist, group, rank, world, send_up, recv_up, send_down, recv_down):
-    """send_up -> rank-1 (its bottom halo), send_down -> rank+1 (its top halo)."""
-    ops = []
+    """send_up -> rank-1 (its bottom halo), send_down -> rank+1 (its top halo).
+
+    nccl (= RCCL) moves the CUDA row blocks directly over xGMI.  On a gloo group (the CPU tests,
+    and multi-process rehearsals on a one-GPU box) CUDA tensors are staged through host memory.
+    """
+    def peer(r):
+        return dist.get_global_rank(group, r) if group is not None else r
+    staged = dist.get_backend(group) == "gloo" and any(t is not None and t.is_cuda
+                                                       for t in (send_up, recv_up, send_down, recv_down))
+    pairs = []
     if rank > 0:
-        ops.append(dist.P2POp(dist.isend, send_up, dist.get_global_rank(group, rank - 1) if group else rank - 1, group))
-        ops.append(dist.P2POp(dist.irecv, recv_up, dist.get_global_rank(group, rank - 1) if group else rank - 1, group))
+        pairs.append((send_up, recv_up, peer(rank - 1)))
     if rank < world - 1:
-        ops.append(dist.P2POp(dist.isend, send_down, dist.get_global_rank(group, rank + 1) if group else rank + 1, group))
-        ops.append(dist.P2POp(dist.irecv, recv_down, dist.get_global_rank(group, rank + 1) if group else rank + 1, group))
+        pairs.append((send_down, recv_down, peer(rank + 1)))
+    ops, back = [], []
+    for snd, rcv, p in pairs:
+        if staged:
+            h_s, h_r = snd.cpu(), rcv.cpu()
+            back.append((rcv, h_r))
+            snd, rcv = h_s, h_r
+        ops.append(dist.P2POp(dist.isend, snd, p, group))
+        ops.append(dist.P2POp(dist.irecv, rcv, p, group))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+    for dst, h in back:
+        dst.copy_(h)
 
 
 def progressive_filter_sharded(Z_band, img_rows, windows, thresholds, *, rank=None, world_size=None, group=None,

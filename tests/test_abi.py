@@ -41,9 +41,11 @@ def test_no_cpu_fallback():
 
 
 def test_product_never_imports_oracle():
+    """only tests/, smoke() and bench.py's cpu_baseline may touch oracle/"""
+    pat = re.compile(r"^\s*(from\s+oracle|import\s+oracle|from\s+\.+oracle)|smrf_oracle|oracle/_ref", re.M)
     pkg = os.path.join(ROOT, "neilpy_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
-                assert "oracle" not in text.replace("smrf_oracle.py", "").lower() or f == "build.py", f
+                assert not pat.search(text), os.path.join(dirpath, f)

@@ -232,3 +232,67 @@ def test_create_dem_stage_golden_all_samples(nz):
         gold = golden("smrf_%s.npz" % name)
         I, t = nz.create_dem(x, y, z, cellsize=1, bin_type="min")
         assert np.array_equal(I, zmin_from_centi(gold["Zmin_centi"]), equal_nan=True)
+
+
+def test_band_calls_match_full_raster(nz, gpu_device):
+    """the row-band form of the C ABI (halo rows present, reflect only at true borders)"""
+    import ctypes as C
+    import torch
+    from neilpy_amd import _lib
+    lib = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(8)
+    for dtype, sfx in ((np.float32, "f32"), (np.float64, "f64")):
+        Zh = rand_dem(rng, (180, 300), dtype)
+        Z = torch.from_numpy(Zh).to(gpu_device)
+        m = Z.shape[0]
+        for r in (1, 5, 18, 33):
+            full_e = nz.erosion(Z, radius=r)
+            full_o = nz.dilation(full_e, radius=r)
+            for b0, b1 in ((0, 90), (90, 180), (40, 130)):
+                lo, hi = max(0, b0 - 2 * r), min(m, b1 + 2 * r)
+                q0, q1 = max(0, b0 - r), min(m, b1 + r)
+                src = Z[lo:hi].contiguous()
+                ero = torch.empty((q1 - q0, Z.shape[1]), dtype=Z.dtype, device=gpu_device)
+                _lib.check(getattr(lib, "smrf_disk_filter_" + sfx)(
+                    C.c_void_p(src.data_ptr()), C.c_void_p(ero.data_ptr()), m, Z.shape[1], Z.shape[1], lo, hi - lo,
+                    q0, q1 - q0, r, 0, 0, 0, st))
+                assert torch.equal(ero, full_e[q0:q1]), (sfx, r, b0)
+                opened = torch.empty((b1 - b0, Z.shape[1]), dtype=Z.dtype, device=gpu_device)
+                mask = torch.zeros((b1 - b0, Z.shape[1]), dtype=torch.uint8, device=gpu_device)
+                when = torch.zeros_like(mask)
+                last = Z[b0:b1].contiguous()
+                _lib.check(getattr(lib, "smrf_pf_dilate_flag_" + sfx)(
+                    C.c_void_p(ero.data_ptr()), C.c_void_p(last.data_ptr()), C.c_void_p(opened.data_ptr()),
+                    C.c_void_p(mask.data_ptr()), C.c_void_p(when.data_ptr()), 0.7, 3, m, Z.shape[1], Z.shape[1],
+                    q0, q1 - q0, b0, b1 - b0, r, 0, 0, st))
+                assert torch.equal(opened, full_o[b0:b1]), (sfx, r, b0)
+                want = ((last - opened).double() > 0.7)
+                assert torch.equal(mask.bool(), want) and torch.equal(when, want.to(torch.uint8) * 3)
+            # a band that lacks halo rows is refused, not silently reflected
+            bad = Z[90:180].contiguous()
+            out = torch.empty_like(bad)
+            rc = getattr(lib, "smrf_disk_filter_" + sfx)(C.c_void_p(bad.data_ptr()), C.c_void_p(out.data_ptr()), m,
+                                                          Z.shape[1], Z.shape[1], 90, 90, 90, 90, r, 0, 0, 0, st)
+            assert rc == -1
+
+
+def test_sharded_two_ranks_on_one_gpu(nz, tmp_path):
+    """bench.py's N=2 path (row bands + halo exchange + HIP band kernels), gloo-staged halos, both
+    ranks on cuda:0; the mask count must equal the single-device run."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    common = ["--n", "1024", "--windows", "12", "--steps", "1", "--warmup", "1", "--no-cpu"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common,
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29611", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--backend", "gloo", "--share-gpu"] + common,
+                         capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert j2["n_gpus"] == 2 and j1["config"]["object_cells"] == j2["config"]["object_cells"]
