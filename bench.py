@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mcells/s through SMRF progressive_filter on a 16384^2 fp32 DEM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 16384] [--windows 50]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 16384] [--windows 50]
 
 A "step" is one full progressive_filter call (all windows: erosion + dilation + flagging per
 window) over the synthetic DEM ``synth_dem(n, seed=20240)`` already resident in HBM.  With N > 1
@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=16384, help="DEM is n x n cells")
+    ap.add_argument("--size", dest="n", type=int, default=16384, help="DEM is size x size cells")
     ap.add_argument("--windows", type=int, default=50, help="radii 1..windows")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--cpu-crop", type=int, default=192, help="crop edge for the CPU baseline (0 = skip)")

@@ -284,7 +284,7 @@ def test_sharded_two_ranks_on_one_gpu(nz, tmp_path):
     import subprocess
     import sys
     from conftest import ROOT
-    common = ["--n", "1024", "--windows", "12", "--steps", "1", "--warmup", "1", "--no-cpu"]
+    common = ["--size", "1024", "--windows", "12", "--steps", "1", "--warmup", "1", "--no-cpu"]
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common,
                          capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
