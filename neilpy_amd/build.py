@@ -49,7 +49,14 @@ def newest_header():
     return t
 
 
-def build(jobs=None, force=False, verbose=True):
+def build(jobs=None, force=False, verbose=True, variant=None, defs=()):
+    """``variant`` builds a side library ``_lib/variants/<variant>.so`` with extra ``defs`` (developer
+    A/B and diagnostic builds; never loaded by the package)."""
+    global OBJ, LIB
+    if variant:
+        OBJ = os.path.join(PKG, "_build", "variant_" + variant)
+        LIB = os.path.join(LIBDIR, "variants", variant + ".so")
+        os.makedirs(os.path.dirname(LIB), exist_ok=True)
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     cc = hipcc()
@@ -64,7 +71,7 @@ def build(jobs=None, force=False, verbose=True):
 
     def compile_one(job):
         obj, src, extra = job
-        cmd = [cc] + FLAGS + extra + ["-c", src, "-o", obj]
+        cmd = [cc] + FLAGS + list(defs) + extra + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), r.stderr[-4000:]))
@@ -92,6 +99,8 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("-j", type=int, default=None)
     ap.add_argument("--force", action="store_true")
+    ap.add_argument("--variant", default=None)
+    ap.add_argument("--defs", default="", help="extra compiler flags for a variant build, space separated")
     a = ap.parse_args()
-    build(a.j, a.force)
+    build(a.j, a.force, variant=a.variant, defs=tuple(a.defs.split()))
     sys.exit(0)

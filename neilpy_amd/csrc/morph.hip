@@ -8,6 +8,13 @@
 
 #include "smrf_common.h"
 
+#ifdef SMRF_STAMPS
+static unsigned long long* g_stamp_buf = nullptr;   // device buffer of 8 counters (diagnostic build)
+extern "C" __attribute__((visibility("default"))) void smrf_debug_set_stamp_buffer(unsigned long long* d_buf) {
+  g_stamp_buf = d_buf;
+}
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------
@@ -151,6 +158,9 @@ int disk_filter(DiskArgs<T> a, bool dilate, int impl, hipStream_t stream) {
     if (a.radius > SMRF_RING_MAX_RADIUS)
       return smrf_fail(SMRF_E_UNSUPPORTED, "ring kernels cover radius <= %d (got %d)", SMRF_RING_MAX_RADIUS, a.radius);
     a.seg = smrf_env_int("SMRF_RING_SEG", 0);   // 0: the launcher sizes segments from its occupancy
+#ifdef SMRF_STAMPS
+    a.dbg = g_stamp_buf;
+#endif
     return RingFn<T>::call(a, dilate, stream);
   }
   if (impl != SMRF_IMPL_DIRECT) return smrf_fail(SMRF_E_ARG, "unknown impl %d", impl);

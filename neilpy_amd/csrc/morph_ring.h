@@ -24,6 +24,9 @@
 
 #include "smrf_common.h"
 
+#ifndef SMRF_RING_TW
+#define SMRF_RING_TW 256   // columns (= lanes) per workgroup: 256 (shared table, barriers) or 64 (wave-private)
+#endif
 #ifndef SMRF_FORCE_OCC
 #define SMRF_OCC_OVERRIDE(...) __VA_ARGS__
 #else
@@ -137,31 +140,34 @@ struct RingCfg {
   static constexpr int E = sizeof(T) / 4;
   static constexpr int J = S::J;
   static constexpr int W = TW + 2 * R;                   // staged cells per row
-  static constexpr int PAD = 1 << (J > 0 ? J - 1 : 0);
+  static constexpr int PAD = 1 << J;                     // furthest build read is < 2^J cells ahead
   static constexpr int WP = ((W + PAD + 3) / 4) * 4;     // pitch of one table level (cells)
+  static constexpr int NPOS = (W + TW - 1) / TW;         // staged cells per lane and row
   static constexpr int ROWS = 2 * NP;                    // input rows per batch
   // table levels: level j holds the min/max over 2^j cells starting at the cell.  A lookup of
-  // half-width w reads level floor(log2(2w+1)); only those levels, plus the steps needed to reach
-  // them two levels at a time, are built and stored.
+  // half-width w reads level floor(log2(2w+1)).  Built in two stages of INDEPENDENT reads (one
+  // LDS round trip and one barrier each): the base level JB straight from the staged row
+  // (2^JB - 1 reads), then every higher level from the base level (stride 2^JB).
   static constexpr bool used(int j) {
     if (j == 0) return true;
     for (int k = 1; k < S::K; ++k)
       if (clog2(2 * S::wk(k) + 1) == j) return true;
     return false;
   }
-  static constexpr int next_level(int cur) {             // build chain: 0 -> ... -> J
-    if (cur + 1 > J) return -1;
-    if (cur + 2 > J || used(cur + 1)) return cur + 1;
-    return cur + 2;
+  static constexpr int jmin() {                          // lowest level >= 1 that a lookup reads
+    for (int j = 1; j <= J; ++j)
+      if (used(j)) return j;
+    return J;
   }
-  static constexpr bool stored(int j) {                  // is level j on the chain?
-    for (int c = 0; c >= 0 && c <= J; c = next_level(c))
-      if (c == j) return true;
-    return false;
-  }
-  static constexpr int slot_of(int j) {                  // storage index of level j
-    int n = 0;
-    for (int c = 0; c >= 0 && c < j; c = next_level(c)) ++n;
+  static constexpr int JB = jmin() < 3 ? jmin() : 3;     // base level
+  static constexpr bool stored(int j) { return j == 0 || (j >= JB && j <= J && (j == JB || used(j))); }
+  // storage index of a stored level; level 0 is double buffered (indices 0 and 1, alternating per
+  // batch) so that staging the next batch never races with a slower wave still reading its cells
+  static constexpr int slot_of(int j) {
+    if (j == 0) return 0;
+    int n = 2;
+    for (int c = 1; c < j; ++c)
+      if (stored(c)) ++n;
     return n;
   }
   static constexpr int NLEV = slot_of(J) + 1;
@@ -171,8 +177,11 @@ struct RingCfg {
   static constexpr int gsize(int g) { int n = S::K - 1 - g * G; return n < 0 ? 0 : (n > G ? G : n); }
   static constexpr int NEED = E * (2 * R + 2 * S::K + 36) + 16;   // measured VGPR demand
   static constexpr int OCC_REG = NEED <= 64 ? 8 : NEED <= 96 ? 5 : NEED <= 128 ? 4 : NEED <= 168 ? 3 : NEED <= 256 ? 2 : 1;
-  static constexpr int OCC_LDS = (int)(160 * 1024 / LDS_BYTES) < 1 ? 1 : (int)(160 * 1024 / LDS_BYTES);
-  static constexpr int OCC = OCC_REG < OCC_LDS ? OCC_REG : OCC_LDS;   // workgroups (= waves/SIMD) per CU
+  static constexpr int WAVES = TW / 64;                  // waves per workgroup
+  static constexpr int WG_LDS = (int)(160 * 1024 / LDS_BYTES) < 1 ? 1 : (int)(160 * 1024 / LDS_BYTES);
+  static constexpr int OCC_LDS = WG_LDS * WAVES / 4 < 1 ? 1 : WG_LDS * WAVES / 4;
+  static constexpr int OCC = OCC_REG < OCC_LDS ? OCC_REG : OCC_LDS;   // waves per SIMD the kernel is built for
+  static constexpr int WG_PER_CU = OCC * 4 / WAVES < 1 ? 1 : OCC * 4 / WAVES;
   // ring slot s (0 .. 2R-3) after a pair takes min3(acc[s+2], RA[kA(s)], RB[kB(s)])
   static constexpr int kA(int s) { int d = R - s - 2; return S::kidx(d < 0 ? -d : d); }
   static constexpr int kB(int s) { int d = R - s - 1; return S::kidx(d < 0 ? -d : d); }
@@ -184,6 +193,30 @@ struct RingCfg {
     return k == 0 ? 0 : (k - 1) / G;
   }
 };
+
+// Diagnostic build only (-DSMRF_STAMPS): per-phase wave-cycle sums, written to a buffer of their own
+// (never read by the kernel, never part of an output).  Not compiled into the product library.
+#ifdef SMRF_STAMPS
+#define SMRF_STAMP_DECL unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_acc[6] = {0, 0, 0, 0, 0, 0};
+#define SMRF_STAMP(i)                                              \
+  do {                                                             \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    const unsigned long long st_t1 = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                            \
+    st_acc[i] += st_t1 - st_t0;                                    \
+    st_t0 = st_t1;                                                 \
+    __builtin_amdgcn_sched_barrier(0);                             \
+  } while (0)
+#define SMRF_STAMP_FLUSH                                                                         \
+  if ((threadIdx.x & 63) == 0 && a.dbg != nullptr) {                                             \
+    for (int i = 0; i < 6; ++i) atomicAdd(&a.dbg[i], st_acc[i]);                                 \
+    atomicAdd(&a.dbg[7], 1ull);                                                                  \
+  }
+#else
+#define SMRF_STAMP_DECL
+#define SMRF_STAMP(i)
+#define SMRF_STAMP_FLUSH
+#endif
 
 // reflect-folded local row index of consecutive global rows without a division per row
 struct RowFold {
@@ -219,10 +252,19 @@ void ring_kernel(const DiskArgs<T> a) {
   const int x = x0 + tid;
   const int ys = a.out_row0 + blockIdx.y * a.seg;        // global output rows [ys, ye)
   const int ye = min(a.out_row0 + a.out_rows, ys + a.seg);
-  const bool has2 = tid < 2 * R;
-  const int c0 = smrf_fold(x0 - R + tid, a.cols);
-  const int c1 = has2 ? smrf_fold(x0 - R + tid + TW, a.cols) : c0;
+  constexpr int NPOS = C::NPOS, W = C::W;
+  // lane-owned staged cells: positions tid + i*TW of the TW+2R wide row; only the last can be absent
+  const bool has_last = tid + (NPOS - 1) * TW < W;
+  int cpos[NPOS];
+#pragma unroll
+  for (int i = 0; i < NPOS; ++i) cpos[i] = smrf_fold(x0 - R + tid + (tid + i * TW < W ? i * TW : 0), a.cols);
   const int last_in = a.in_rows - 1;
+  // workgroup-wide when the table is shared by several waves; a single-wave workgroup owns its
+  // table and only has to keep the compiler from moving LDS accesses across the phase boundary
+  auto phase_sync = [&]() {
+    if constexpr (TW > 64) __syncthreads();
+    else { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+  };
   const bool flag = a.mask != nullptr;
   const int xc = x < a.cols ? x : a.cols - 1;
   const unsigned lds_q = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(L + tid + R);
@@ -232,7 +274,7 @@ void ring_kernel(const DiskArgs<T> a) {
 #pragma unroll
   for (int i = 0; i < 2 * R; ++i) acc[i] = ident<T>(DIL);
 
-  T2 pf0[NP], pf1[NP];                                   // next batch, cells tid and tid + TW
+  T2 pf[NP][NPOS];                                       // next batch, this lane's staged cells
   T outv[ROWS], lastv[ROWS];
 #pragma unroll
   for (int i = 0; i < ROWS; ++i) { outv[i] = T(0); lastv[i] = T(0); }
@@ -247,8 +289,8 @@ void ring_kernel(const DiskArgs<T> a) {
       lb = lb < 0 ? 0 : (lb > last_in ? last_in : lb);
       const T* ra = a.in + (long long)la * a.ld;
       const T* rb = a.in + (long long)lb * a.ld;
-      pf0[p].x = ra[c0]; pf0[p].y = rb[c0];
-      pf1[p].x = ra[c1]; pf1[p].y = rb[c1];
+#pragma unroll
+      for (int i = 0; i < NPOS; ++i) { pf[p][i].x = ra[cpos[i]]; pf[p][i].y = rb[cpos[i]]; }
     }
     rf.advance(ROWS);
   };
@@ -289,53 +331,101 @@ void ring_kernel(const DiskArgs<T> a) {
   };
 
   prefetch();
-  for (int yy0 = ys - R; yy0 < ye + R; yy0 += ROWS) {
-    T2 v0[NP], v1[NP];
+  SMRF_STAMP_DECL
+  constexpr int JB = C::JB, SB = C::slot_of(JB);
+  int par = 0;                                           // which level-0 copy this batch uses
+  for (int yy0 = ys - R; yy0 < ye + R; yy0 += ROWS, par ^= 1) {
+    // (1) stage the prefetched rows into this batch's level-0 copy.  The other copy may still be
+    //     read by a slower wave (its own cells of the previous batch); the higher levels are only
+    //     written after the barrier below, which every wave reaches after its previous consume.
+    T2 v[NP][NPOS];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      v0[p] = pf0[p];
-      v1[p] = pf1[p];
-      L[p * NLEV * WP + tid] = v0[p];
-      if (has2) L[p * NLEV * WP + tid + TW] = v1[p];
+#pragma unroll
+      for (int i = 0; i < NPOS; ++i) {
+        v[p][i] = pf[p][i];
+        if (i < NPOS - 1 || has_last) L[(p * NLEV + par) * WP + tid + i * TW] = v[p][i];
+      }
     }
-    __syncthreads();
+    phase_sync();
+    SMRF_STAMP(0);                                         // wait for prefetch + stage to LDS + barrier
     if (yy0 > ys - R) epilogue(yy0 - ROWS);
     if (yy0 + ROWS < ye + R) prefetch();
     load_last(yy0);
+    SMRF_STAMP(1);                                         // epilogue stores + issue of next loads
 
-    // table build along the chain 0 -> ... -> J, one or two levels per barrier
-    [&]<int... CI>(std::integer_sequence<int, CI...>) {
-      (([&] {
-         constexpr int cur = []() { int c = 0; for (int i = 0; i < CI; ++i) c = C::next_level(c); return c; }();
-         constexpr int nxt = C::next_level(cur);
-         static_assert(nxt > cur && nxt <= J, "bad level chain");
-         constexpr int h = 1 << cur;
-         constexpr int scur = C::slot_of(cur), snxt = C::slot_of(nxt);   // forced compile-time
+    // (2) base level JB from level 0: 2^JB - 1 independent reads per cell
 #pragma unroll
-         for (int p = 0; p < NP; ++p) {
-           const T2* Lm = L + (p * NLEV + scur) * WP;
-           T2* Ln = L + (p * NLEV + snxt) * WP;
-           T2 n0 = Lm[tid + h];
-           v0[p].x = op2<DIL>(v0[p].x, n0.x); v0[p].y = op2<DIL>(v0[p].y, n0.y);
-           if constexpr (nxt == cur + 2) {
-             const T2 n1 = Lm[tid + 2 * h], n2 = Lm[tid + 3 * h];
-             v0[p].x = op3<DIL>(v0[p].x, n1.x, n2.x); v0[p].y = op3<DIL>(v0[p].y, n1.y, n2.y);
-           }
-           Ln[tid] = v0[p];
-           if (has2) {
-             n0 = Lm[tid + TW + h];
-             v1[p].x = op2<DIL>(v1[p].x, n0.x); v1[p].y = op2<DIL>(v1[p].y, n0.y);
-             if constexpr (nxt == cur + 2) {
-               const T2 n1 = Lm[tid + TW + 2 * h], n2 = Lm[tid + TW + 3 * h];
-               v1[p].x = op3<DIL>(v1[p].x, n1.x, n2.x); v1[p].y = op3<DIL>(v1[p].y, n1.y, n2.y);
-             }
-             Ln[tid + TW] = v1[p];
-           }
-         }
-         __syncthreads();
-       }()), ...);
-    }(std::make_integer_sequence<int, C::NLEV - 1>{});
+    for (int p = 0; p < NP; ++p) {
+      const T2* L0 = L + (p * NLEV + par) * WP;
+      T2* LB = L + (p * NLEV + SB) * WP;
+#pragma unroll
+      for (int i = 0; i < NPOS; ++i) {
+        if (i < NPOS - 1 || has_last) {
+          const int pos = tid + i * TW;
+          T2 n[(1 << JB) - 1];
+#pragma unroll
+          for (int k = 1; k < (1 << JB); ++k) n[k - 1] = L0[pos + k];
+          T2 m = v[p][i];
+          if constexpr (JB == 1) { m.x = op2<DIL>(m.x, n[0].x); m.y = op2<DIL>(m.y, n[0].y); }
+          if constexpr (JB >= 2) {
+            m.x = op3<DIL>(m.x, n[0].x, n[1].x); m.y = op3<DIL>(m.y, n[0].y, n[1].y);
+            m.x = op2<DIL>(m.x, n[2].x); m.y = op2<DIL>(m.y, n[2].y);
+          }
+          if constexpr (JB == 3) {
+            m.x = op3<DIL>(m.x, n[3].x, n[4].x); m.y = op3<DIL>(m.y, n[3].y, n[4].y);
+            m.x = op3<DIL>(m.x, n[5].x, n[6].x); m.y = op3<DIL>(m.y, n[5].y, n[6].y);
+          }
+          v[p][i] = m;
+          LB[pos] = m;
+        }
+      }
+    }
+    phase_sync();
+    // (3) levels JB+1 .. J from the base level: cells pos + k * 2^JB, k < 2^(J-JB)
+    if constexpr (J > JB) {
+      constexpr int NB = (1 << (J - JB)) - 1;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const T2* LB = L + (p * NLEV + SB) * WP;
+#pragma unroll
+        for (int i = 0; i < NPOS; ++i) {
+          if (i < NPOS - 1 || has_last) {
+            const int pos = tid + i * TW;
+            T2 n[NB];
+#pragma unroll
+            for (int k = 1; k <= NB; ++k) n[k - 1] = LB[pos + (k << JB)];
+            T2 m = v[p][i];
+            [&]<int... JJ>(std::integer_sequence<int, JJ...>) {
+              (([&] {
+                 constexpr int j = JB + 1 + JJ;            // level being completed
+                 constexpr int k0 = 1 << (j - 1 - JB);     // new cells k0 .. 2*k0 - 1
+                 if constexpr (k0 == 1) { m.x = op2<DIL>(m.x, n[0].x); m.y = op2<DIL>(m.y, n[0].y); }
+                 else {
+#pragma unroll
+                   for (int k = k0; k < 2 * k0; k += 2) {
+                     m.x = op3<DIL>(m.x, n[k - 1].x, n[k].x); m.y = op3<DIL>(m.y, n[k - 1].y, n[k].y);
+                   }
+                 }
+                 if constexpr (C::stored(j)) {
+                   constexpr int sj = C::slot_of(j);
+                   L[(p * NLEV + sj) * WP + pos] = m;
+                 }
+               }()), ...);
+            }(std::make_integer_sequence<int, J - JB>{});
+          }
+        }
+      }
+      phase_sync();
+    }
+    SMRF_STAMP(2);                                         // table build incl. its barriers
 
+    // (4) consume: window lookups + ring update, pair by pair
+    T2 own[NP];                                            // the lane's own cells (level 0)
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+      own[p] = lds_read2<0>(lds_q + (p * NLEV + par) * WP * (unsigned)sizeof(T2), T());
+    lds_wait<0>();
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const unsigned q = lds_q + p * NLEV * WP * (unsigned)sizeof(T2);   // this lane's cell, level 0
@@ -378,11 +468,9 @@ void ring_kernel(const DiskArgs<T> a) {
         }(std::make_integer_sequence<int, (2 * R - 2 > 0 ? 2 * R - 2 : 0)>{});
       };
 
-      const T2 c = lds_read2<0>(q, T());
       if constexpr (NG > 0) issue(std::integral_constant<int, 0>{});
-      lds_wait<2 * C::gsize(0)>();
-      ra[0] = c.x;
-      rb[0] = c.y;
+      ra[0] = own[p].x;
+      rb[0] = own[p].y;
       // the two rows this pair completes (before their slots are overwritten)
       outv[2 * p] = op2<DIL>(acc[0], ra[0]);
       [&]<int... GI>(std::integer_sequence<int, GI...>) {
@@ -401,9 +489,10 @@ void ring_kernel(const DiskArgs<T> a) {
       acc[2 * R - 2] = op2<DIL>(ra[0], rb[KR1]);
       acc[2 * R - 1] = rb[0];
       __builtin_amdgcn_sched_barrier(0);
+      SMRF_STAMP(3);                                       // lookups + ring update of one pair
     }
-    __syncthreads();
   }
+  SMRF_STAMP_FLUSH
   {
     const int nb = (ye + R - (ys - R) + ROWS - 1) / ROWS;
     epilogue(ys - R + (nb - 1) * ROWS);
@@ -412,7 +501,7 @@ void ring_kernel(const DiskArgs<T> a) {
 
 template <typename T, int R, bool DIL>
 int ring_launch(const DiskArgs<T>& a_in, hipStream_t stream) {
-  constexpr int TW = 256;
+  constexpr int TW = SMRF_RING_TW;
   constexpr int NP = sizeof(T) == 4 ? 2 : 1;
   using C = RingCfg<T, R, TW, NP>;
   auto kern = ring_kernel<T, R, DIL, TW, NP>;
@@ -429,7 +518,7 @@ int ring_launch(const DiskArgs<T>& a_in, hipStream_t stream) {
     // output rows per workgroup: about `rounds` full waves of resident workgroups (OCC per CU on
     // 256 CUs), but segments long enough that the 2R halo rows each one re-reads stay a small part
     const int rounds = smrf_env_int("SMRF_RING_ROUNDS", 2);
-    const int nseg = std::max(1, (rounds * C::OCC * 256 + strips / 2) / strips);
+    const int nseg = std::max(1, (rounds * C::WG_PER_CU * 256 + strips / 2) / strips);
     int seg = (a.out_rows + nseg - 1) / nseg;
     seg = std::max(seg, std::max(32, 4 * R));
     seg = std::min(seg, a.out_rows);

@@ -58,6 +58,7 @@ struct DiskArgs {
   int radius;
   int nan_aware;
   int seg;            // output rows per workgroup (ring kernels)
+  unsigned long long* dbg;   // diagnostic builds only (SMRF_STAMPS): 8 counters, else NULL
 };
 
 // ring-kernel dispatchers, one per (dtype, radius % SMRF_RING_PARTS); defined in ring_part.hip
