@@ -9,7 +9,7 @@
 #include "smrf_common.h"
 
 #ifdef SMRF_STAMPS
-static unsigned long long* g_stamp_buf = nullptr;   // device buffer of 8 counters (diagnostic build)
+static unsigned long long* g_stamp_buf = nullptr;   // device buffer of 16 counters (diagnostic build)
 extern "C" __attribute__((visibility("default"))) void smrf_debug_set_stamp_buffer(unsigned long long* d_buf) {
   g_stamp_buf = d_buf;
 }

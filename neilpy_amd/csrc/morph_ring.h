@@ -27,6 +27,11 @@
 #ifndef SMRF_RING_TW
 #define SMRF_RING_TW 256   // columns (= lanes) per workgroup: 256 (shared table, barriers) or 64 (wave-private)
 #endif
+// lookup groups in flight: a third buffer (+16 VGPRs in fp32) only where the kernel sits at 2 waves/SIMD
+// anyway (demand above 168 VGPRs) and the extra registers do not cost a wave
+#ifndef SMRF_RING_DEPTH
+#define SMRF_RING_DEPTH(need) 2   /* measured: a third group in flight gains nothing (lookups are not the exposed latency) */
+#endif
 #ifndef SMRF_FORCE_OCC
 #define SMRF_OCC_OVERRIDE(...) __VA_ARGS__
 #else
@@ -128,7 +133,7 @@ __device__ __forceinline__ Vec2<double>::type lds_read2(unsigned addr, double) {
 }
 template <int N>
 __device__ __forceinline__ void lds_wait() {   // at most N LDS operations still outstanding
-  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N > 15 ? 15 : N) : "memory");   // 4-bit counter field
 }
 
 // Geometry of one kernel instance.  Input rows are handled in PAIRS (A = y, B = y+1): the two
@@ -175,7 +180,14 @@ struct RingCfg {
   static constexpr int G = 4;                            // window lookups per pipelined group
   static constexpr int NG = (S::K - 1 + G - 1) / G;      // groups for k = 1..K-1
   static constexpr int gsize(int g) { int n = S::K - 1 - g * G; return n < 0 ? 0 : (n > G ? G : n); }
-  static constexpr int NEED = E * (2 * R + 2 * S::K + 36) + 16;   // measured VGPR demand
+  static constexpr int NEED_BASE = E * (2 * R + 2 * S::K + 36) + 16;   // measured VGPR demand at D = 2
+  static constexpr int D = SMRF_RING_DEPTH(NEED_BASE);   // lookup groups kept in flight
+  static constexpr int inflight_after(int g) {           // lookups of groups g+1 .. g+D-1
+    int n = 0;
+    for (int i = 1; i < D; ++i) n += gsize(g + i);
+    return n;
+  }
+  static constexpr int NEED = NEED_BASE + (D - 2) * 4 * G * E;
   static constexpr int OCC_REG = NEED <= 64 ? 8 : NEED <= 96 ? 5 : NEED <= 128 ? 4 : NEED <= 168 ? 3 : NEED <= 256 ? 2 : 1;
   static constexpr int WAVES = TW / 64;                  // waves per workgroup
   static constexpr int WG_LDS = (int)(160 * 1024 / LDS_BYTES) < 1 ? 1 : (int)(160 * 1024 / LDS_BYTES);
@@ -197,7 +209,7 @@ struct RingCfg {
 // Diagnostic build only (-DSMRF_STAMPS): per-phase wave-cycle sums, written to a buffer of their own
 // (never read by the kernel, never part of an output).  Not compiled into the product library.
 #ifdef SMRF_STAMPS
-#define SMRF_STAMP_DECL unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_acc[6] = {0, 0, 0, 0, 0, 0};
+#define SMRF_STAMP_DECL unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define SMRF_STAMP(i)                                              \
   do {                                                             \
     __builtin_amdgcn_sched_barrier(0);                             \
@@ -209,8 +221,8 @@ struct RingCfg {
   } while (0)
 #define SMRF_STAMP_FLUSH                                                                         \
   if ((threadIdx.x & 63) == 0 && a.dbg != nullptr) {                                             \
-    for (int i = 0; i < 6; ++i) atomicAdd(&a.dbg[i], st_acc[i]);                                 \
-    atomicAdd(&a.dbg[7], 1ull);                                                                  \
+    for (int i = 0; i < 10; ++i) atomicAdd(&a.dbg[i], st_acc[i]);                                 \
+    atomicAdd(&a.dbg[15], 1ull);                                                                  \
   }
 #else
 #define SMRF_STAMP_DECL
@@ -242,7 +254,7 @@ void ring_kernel(const DiskArgs<T> a) {
   using C = RingCfg<T, R, TW, NP>;
   using S = typename C::S;
   using T2 = typename Vec2<T>::type;
-  constexpr int J = S::J, K = S::K, WP = C::WP, G = C::G, NG = C::NG, ROWS = C::ROWS, NLEV = C::NLEV;
+  constexpr int J = S::J, K = S::K, WP = C::WP, G = C::G, NG = C::NG, ROWS = C::ROWS, NLEV = C::NLEV, D = C::D;
   constexpr int KR1 = S::kidx(R - 1);                   // width index of dy = +-(R-1)
   extern __shared__ __attribute__((aligned(16))) unsigned char smrf_lds[];
   T2* const L = reinterpret_cast<T2*>(smrf_lds);         // [NP][NLEV][WP] of {row A, row B}
@@ -279,54 +291,85 @@ void ring_kernel(const DiskArgs<T> a) {
 #pragma unroll
   for (int i = 0; i < ROWS; ++i) { outv[i] = T(0); lastv[i] = T(0); }
 
-  RowFold rf(ys - R, a.img_rows);                        // tracks the NEXT batch to prefetch
+  // The row loop starts DELTA rows early so that the ROWS outputs a batch completes are either all
+  // at or above ys or all below it (rows before ys - R only feed outputs that are never written).
+  constexpr int DELTA = (ROWS - (2 * R) % ROWS) % ROWS;
+  const int ystart = ys - R - DELTA;
+  RowFold rf(ystart, a.img_rows);                        // tracks the NEXT batch to prefetch
   auto prefetch = [&]() {
+    const int l0 = rf.p - a.in_row0;
+    if (rf.p + ROWS <= rf.n && l0 >= 0 && l0 + ROWS - 1 <= last_in) {
+      // common case: ROWS consecutive rows inside the band, no reflection: one address, row strides
+      const T* r0 = a.in + (long long)l0 * a.ld;
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      int la = rf.at(2 * p) - a.in_row0;
-      int lb = rf.at(2 * p + 1) - a.in_row0;
-      la = la < 0 ? 0 : (la > last_in ? last_in : la);   // only rows past the segment's halo clamp
-      lb = lb < 0 ? 0 : (lb > last_in ? last_in : lb);
-      const T* ra = a.in + (long long)la * a.ld;
-      const T* rb = a.in + (long long)lb * a.ld;
+      for (int p = 0; p < NP; ++p) {
 #pragma unroll
-      for (int i = 0; i < NPOS; ++i) { pf[p][i].x = ra[cpos[i]]; pf[p][i].y = rb[cpos[i]]; }
+        for (int i = 0; i < NPOS; ++i) {
+          pf[p][i].x = r0[(long long)(2 * p) * a.ld + cpos[i]];
+          pf[p][i].y = r0[(long long)(2 * p + 1) * a.ld + cpos[i]];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        int la = rf.at(2 * p) - a.in_row0;
+        int lb = rf.at(2 * p + 1) - a.in_row0;
+        la = la < 0 ? 0 : (la > last_in ? last_in : la);   // only rows outside the segment's halo clamp
+        lb = lb < 0 ? 0 : (lb > last_in ? last_in : lb);
+        const T* ra = a.in + (long long)la * a.ld;
+        const T* rb = a.in + (long long)lb * a.ld;
+#pragma unroll
+        for (int i = 0; i < NPOS; ++i) { pf[p][i].x = ra[cpos[i]]; pf[p][i].y = rb[cpos[i]]; }
+      }
     }
     rf.advance(ROWS);
+  };
+  // one completed output cell: NaN rule, store, flag step
+  auto emit = [&](int yo, long long off, T val, T lastval) {
+    if (a.nan_aware) {
+      // scipy: the first visited footprint element (offset (-R, 0)) decides NaN-ness
+      const int ly = smrf_fold(yo - R, a.img_rows) - a.in_row0;
+      const T first = a.in[(long long)ly * a.ld + x];
+      if (first != first) val = qnan<T>();
+    }
+    a.out[off] = val;
+    if (flag) {
+      const T diff = lastval - val;                        // raster dtype
+      if ((double)diff > a.thr) {                          // float64 comparison (NumPy 2)
+        a.mask[off] = 1;
+        if (a.when != nullptr) a.when[off] = (uint8_t)a.widx;
+      }
+    }
   };
   // outputs of the batch whose first input row was yyb; written one iteration late so that no
   // store is younger than the prefetch loads the loop waits for
   auto epilogue = [&](int yyb) {
+    const int yob = yyb - R;                               // first output row of the batch
+    if (yob < ys || x >= a.cols) return;                   // (aligned: yob < ys means all rows are)
+    const long long off0 = (long long)(yob - a.out_row0) * a.ld + x;
+    if (yob + ROWS <= ye) {
 #pragma unroll
-    for (int i = 0; i < ROWS; ++i) {
-      const int yo = yyb + i - R;
-      if (yo >= ys && yo < ye && x < a.cols) {
-        T val = outv[i];
-        const long long off = (long long)(yo - a.out_row0) * a.ld + x;
-        if (a.nan_aware) {
-          // scipy: the first visited footprint element (offset (-R, 0)) decides NaN-ness
-          const int ly = smrf_fold(yo - R, a.img_rows) - a.in_row0;
-          const T first = a.in[(long long)ly * a.ld + x];
-          if (first != first) val = qnan<T>();
-        }
-        a.out[off] = val;
-        if (flag) {
-          const T diff = lastv[i] - val;                  // raster dtype
-          if ((double)diff > a.thr) {                     // float64 comparison (NumPy 2)
-            a.mask[off] = 1;
-            if (a.when != nullptr) a.when[off] = (uint8_t)a.widx;
-          }
-        }
-      }
+      for (int i = 0; i < ROWS; ++i) emit(yob + i, off0 + (long long)i * a.ld, outv[i], lastv[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < ROWS; ++i)
+        if (yob + i < ye) emit(yob + i, off0 + (long long)i * a.ld, outv[i], lastv[i]);
     }
   };
   auto load_last = [&](int yyb) {
     if (!flag) return;
+    const int y0 = yyb - R - a.out_row0;
+    if (y0 >= 0 && y0 + ROWS <= a.out_rows) {
+      const T* l0 = a.last + (long long)y0 * a.ld + xc;
 #pragma unroll
-    for (int i = 0; i < ROWS; ++i) {
-      int yo = yyb + i - R - a.out_row0;
-      yo = yo < 0 ? 0 : (yo >= a.out_rows ? a.out_rows - 1 : yo);
-      lastv[i] = a.last[(long long)yo * a.ld + xc];
+      for (int i = 0; i < ROWS; ++i) lastv[i] = l0[(long long)i * a.ld];
+    } else {
+#pragma unroll
+      for (int i = 0; i < ROWS; ++i) {
+        int yo = y0 + i;
+        yo = yo < 0 ? 0 : (yo >= a.out_rows ? a.out_rows - 1 : yo);
+        lastv[i] = a.last[(long long)yo * a.ld + xc];
+      }
     }
   };
 
@@ -334,7 +377,7 @@ void ring_kernel(const DiskArgs<T> a) {
   SMRF_STAMP_DECL
   constexpr int JB = C::JB, SB = C::slot_of(JB);
   int par = 0;                                           // which level-0 copy this batch uses
-  for (int yy0 = ys - R; yy0 < ye + R; yy0 += ROWS, par ^= 1) {
+  for (int yy0 = ystart; yy0 < ye + R; yy0 += ROWS, par ^= 1) {
     // (1) stage the prefetched rows into this batch's level-0 copy.  The other copy may still be
     //     read by a slower wave (its own cells of the previous batch); the higher levels are only
     //     written after the barrier below, which every wave reaches after its previous consume.
@@ -347,12 +390,14 @@ void ring_kernel(const DiskArgs<T> a) {
         if (i < NPOS - 1 || has_last) L[(p * NLEV + par) * WP + tid + i * TW] = v[p][i];
       }
     }
+    SMRF_STAMP(0);                                         // wait for prefetched rows + LDS stage writes
     phase_sync();
-    SMRF_STAMP(0);                                         // wait for prefetch + stage to LDS + barrier
-    if (yy0 > ys - R) epilogue(yy0 - ROWS);
+    SMRF_STAMP(1);                                         // barrier 1
+    if (yy0 > ystart) epilogue(yy0 - ROWS);
+    SMRF_STAMP(2);                                         // epilogue stores
     if (yy0 + ROWS < ye + R) prefetch();
     load_last(yy0);
-    SMRF_STAMP(1);                                         // epilogue stores + issue of next loads
+    SMRF_STAMP(3);                                         // issue of next loads
 
     // (2) base level JB from level 0: 2^JB - 1 independent reads per cell
 #pragma unroll
@@ -381,7 +426,9 @@ void ring_kernel(const DiskArgs<T> a) {
         }
       }
     }
+    SMRF_STAMP(4);                                         // base level
     phase_sync();
+    SMRF_STAMP(5);                                         // barrier 2
     // (3) levels JB+1 .. J from the base level: cells pos + k * 2^JB, k < 2^(J-JB)
     if constexpr (J > JB) {
       constexpr int NB = (1 << (J - JB)) - 1;
@@ -416,9 +463,10 @@ void ring_kernel(const DiskArgs<T> a) {
           }
         }
       }
+      SMRF_STAMP(6);                                       // higher levels
       phase_sync();
+      SMRF_STAMP(7);                                       // barrier 3
     }
-    SMRF_STAMP(2);                                         // table build incl. its barriers
 
     // (4) consume: window lookups + ring update, pair by pair
     T2 own[NP];                                            // the lane's own cells (level 0)
@@ -430,7 +478,7 @@ void ring_kernel(const DiskArgs<T> a) {
     for (int p = 0; p < NP; ++p) {
       const unsigned q = lds_q + p * NLEV * WP * (unsigned)sizeof(T2);   // this lane's cell, level 0
       T ra[K], rb[K];                                      // window results of row A / row B per width
-      T2 ta[2][G], tb[2][G];
+      T2 ta[D][G], tb[D][G];                              // D lookup groups in flight
       auto issue = [&]<int GI>(std::integral_constant<int, GI>) {
         [&]<int... I>(std::integer_sequence<int, I...>) {
           (([&] {
@@ -440,8 +488,8 @@ void ring_kernel(const DiskArgs<T> a) {
                constexpr int j = clog2(2 * w + 1);
                constexpr int base = C::slot_of(j) * WP;
                static_assert(C::stored(j), "lookup level not built");
-               ta[GI & 1][I] = lds_read2<(base - w) * (int)sizeof(T2)>(q, T());
-               tb[GI & 1][I] = lds_read2<(base + w - (1 << j) + 1) * (int)sizeof(T2)>(q, T());
+               ta[GI % D][I] = lds_read2<(base - w) * (int)sizeof(T2)>(q, T());
+               tb[GI % D][I] = lds_read2<(base + w - (1 << j) + 1) * (int)sizeof(T2)>(q, T());
              }
            }()), ...);
         }(std::make_integer_sequence<int, G>{});
@@ -451,8 +499,8 @@ void ring_kernel(const DiskArgs<T> a) {
           (([&] {
              constexpr int k = 1 + GI * G + I;
              if constexpr (k < K) {
-               ra[k] = op2<DIL>(ta[GI & 1][I].x, tb[GI & 1][I].x);
-               rb[k] = op2<DIL>(ta[GI & 1][I].y, tb[GI & 1][I].y);
+               ra[k] = op2<DIL>(ta[GI % D][I].x, tb[GI % D][I].x);
+               rb[k] = op2<DIL>(ta[GI % D][I].y, tb[GI % D][I].y);
              }
            }()), ...);
         }(std::make_integer_sequence<int, G>{});
@@ -468,15 +516,17 @@ void ring_kernel(const DiskArgs<T> a) {
         }(std::make_integer_sequence<int, (2 * R - 2 > 0 ? 2 * R - 2 : 0)>{});
       };
 
-      if constexpr (NG > 0) issue(std::integral_constant<int, 0>{});
+      [&]<int... GI>(std::integer_sequence<int, GI...>) {   // prologue: the first D-1 groups
+        (([&] { if constexpr (GI < NG) issue(std::integral_constant<int, GI>{}); }()), ...);
+      }(std::make_integer_sequence<int, D - 1>{});
       ra[0] = own[p].x;
       rb[0] = own[p].y;
       // the two rows this pair completes (before their slots are overwritten)
       outv[2 * p] = op2<DIL>(acc[0], ra[0]);
       [&]<int... GI>(std::integer_sequence<int, GI...>) {
         (([&] {
-           if constexpr (GI + 1 < NG) issue(std::integral_constant<int, GI + 1>{});
-           lds_wait<2 * C::gsize(GI + 1)>();
+           if constexpr (GI + D - 1 < NG) issue(std::integral_constant<int, GI + D - 1>{});
+           lds_wait<2 * C::inflight_after(GI)>();           // reads of the groups issued after group GI
            reduce(std::integral_constant<int, GI>{});
            if constexpr (GI == 0) {
              if constexpr (R >= 2) outv[2 * p + 1] = op3<DIL>(acc[1], ra[KR1], rb[0]);
@@ -489,13 +539,13 @@ void ring_kernel(const DiskArgs<T> a) {
       acc[2 * R - 2] = op2<DIL>(ra[0], rb[KR1]);
       acc[2 * R - 1] = rb[0];
       __builtin_amdgcn_sched_barrier(0);
-      SMRF_STAMP(3);                                       // lookups + ring update of one pair
+      SMRF_STAMP(8);                                       // lookups + ring update of one pair
     }
   }
   SMRF_STAMP_FLUSH
   {
-    const int nb = (ye + R - (ys - R) + ROWS - 1) / ROWS;
-    epilogue(ys - R + (nb - 1) * ROWS);
+    const int nb = (ye + R - ystart + ROWS - 1) / ROWS;
+    epilogue(ystart + (nb - 1) * ROWS);
   }
 }
 

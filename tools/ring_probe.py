@@ -50,7 +50,7 @@ def main():
     for path in [v for v in a.libs.split(",") if v]:
         if "stamps" in path:
             stamp_lib = C.CDLL(os.path.abspath(path))
-            sbuf = torch.zeros(8, dtype=torch.int64, device="cuda")
+            sbuf = torch.zeros(16, dtype=torch.int64, device="cuda")
             stamp_lib.smrf_debug_set_stamp_buffer.argtypes = [C.c_void_p]
             stamp_lib.smrf_debug_set_stamp_buffer(C.c_void_p(sbuf.data_ptr()))
     for r in [int(v) for v in a.radii.split(",")]:
@@ -74,11 +74,11 @@ def main():
                   (r, name, t, n * n * 2 * elem / t / 1e6, n * n / t / 1e6), flush=True)
         if stamp_lib is not None:
             v = sbuf.cpu().numpy().astype(np.float64)
-            tot = v[:5].sum()
-            names = ["stage+barrier", "epilogue+prefetch", "build", "consume(pairs)", "end barrier"]
-            print("      stamps (share of wave cycles, %d waves): " % int(v[7]) +
-                  "  ".join("%s %.1f%%" % (nm, 100 * x / tot) for nm, x in zip(names, v[:5])) +
-                  "  | cycles/wave %.3g" % (tot / max(v[7], 1)), flush=True)
+            tot = v[:10].sum()
+            names = ["wait-pf+stage", "bar1", "epilogue", "issue-loads", "baseLvl", "bar2", "hiLvls", "bar3", "consume", "-"]
+            print("      stamps (share of wave cycles, %d waves): " % int(v[15]) +
+                  "  ".join("%s %.1f%%" % (nm, 100 * x / tot) for nm, x in zip(names, v[:9])) +
+                  "  | cycles/wave %.3g" % (tot / max(v[15], 1)), flush=True)
 
 
 if __name__ == "__main__":
