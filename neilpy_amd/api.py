@@ -315,11 +315,10 @@ def smrf(x, y, z, cellsize=1, windows=5, slope_threshold=.15, elevation_threshol
 
     Same arguments, defaults and results as neilpy.smrf.  Gridding, both inpaints, both
     progressive filters and the slope raster run on the GPU with the rasters resident in HBM
-    between stages; the bicubic spline evaluation of the tail (:1768-1790) is SciPy's FITPACK on
-    the host, as in the reference ("what comes next").
+    between stages, and so do the bicubic spline solve / evaluation and the point test of the tail
+    (:1768-1795); only 1-D knot vectors and banded LU factors are prepared on the host.
     """
     torch = _torch()
-    from scipy import interpolate
     if np.isscalar(windows):
         windows = np.arange(windows) + 1
     xd, yd, zd = _points_to_device(x, y, z)
@@ -342,25 +341,49 @@ def smrf(x, y, z, cellsize=1, windows=5, slope_threshold=.15, elevation_threshol
     _springs_device(Zmin, "inpaint2")                                               # :1764
     Zpro_d = Zmin
     rows, cols = Zpro_d.shape
+    if rows < 4 or cols < 4:
+        raise ValueError("the bicubic spline of the point classification needs at least 4 x 4 cells")
     S_d = torch.empty_like(Zpro_d)
-    _lib.check(lib.smrf_gradient_slope_f64(_ptr(Zpro_d), _ptr(S_d), rows, cols, float(cellsize), _stream()))
-    Zpro = Zpro_d.cpu().numpy()
-    S = S_d.cpu().numpy()
+    _lib.check(lib.smrf_gradient_slope_f64(_ptr(Zpro_d), _ptr(S_d), rows, cols, float(cellsize), _stream()))   # :1785-1786
 
-    xh = x if not _is_tensor(x) else x.cpu().numpy()
-    yh = y if not _is_tensor(y) else y.cpu().numpy()
+    # RectBivariateSpline(row_centers, col_centers, .).ev(r, c) for Zpro and S on the device (:1768-1790)
+    from . import spline as _spline
+    h_inv = (C.c_double * 6)(*[float(v) for v in tuple(~t)[:6]])
+    c_d, r_d = torch.empty_like(xd), torch.empty_like(xd)
+    _lib.check(lib.smrf_affine_apply_f64(_ptr(xd), _ptr(yd), xd.numel(), h_inv, _ptr(c_d), _ptr(r_d), _stream()))  # :1772
+    tx, lur = _spline.axis_factors(rows)
+    ty, luc = _spline.axis_factors(cols)
+    tx_d, ty_d = torch.from_numpy(tx).to(Zpro_d.device), torch.from_numpy(ty).to(Zpro_d.device)
+    lur_d, luc_d = torch.from_numpy(lur).to(Zpro_d.device), torch.from_numpy(luc).to(Zpro_d.device)
+    npts = xd.numel()
+    vals = []
+    for plane in (Zpro_d, S_d):
+        coef = plane.clone()
+        _lib.check(lib.smrf_spline_solve_f64(_ptr(coef), rows, cols, _ptr(lur_d), _ptr(luc_d), _stream()))
+        out = torch.empty(npts, dtype=torch.float64, device=Zpro_d.device)
+        _lib.check(lib.smrf_spline_eval_f64(_ptr(coef), rows, cols, _ptr(tx_d), _ptr(ty_d), _ptr(r_d), _ptr(c_d), npts,
+                                            _ptr(out), _stream()))
+        vals.append(out)
+    elev_d, slope_d = vals
+    isobj_d = torch.empty(npts, dtype=torch.uint8, device=Zpro_d.device)
+    _lib.check(lib.smrf_classify_points_f64(_ptr(elev_d), _ptr(slope_d), _ptr(zd), npts, float(elevation_threshold),
+                                            float(elevation_scaler), _ptr(isobj_d), _stream()))      # :1794-1795
+    Zpro = Zpro_d.cpu().numpy()
+    is_object_point = isobj_d.cpu().numpy().astype(bool)
+    elevation_values = elev_d.cpu().numpy()
+    last_stats["tail"] = dict(elevation_values=elevation_values, slope_values=slope_d.cpu().numpy())
     zh = z if not _is_tensor(z) else z.cpu().numpy()
-    col_centers = np.arange(0.5, cols + .5)                                         # :1768-1769
-    row_centers = np.arange(0.5, rows + .5)
-    c, r = ~t * (xh, yh)                                                            # :1772
-    elevation_values = interpolate.RectBivariateSpline(row_centers, col_centers, Zpro).ev(r, c)
-    slope_values = interpolate.RectBivariateSpline(row_centers, col_centers, S).ev(r, c)
-    required_value = elevation_threshold + (elevation_scaler * slope_values)        # :1794
-    is_object_point = np.abs(elevation_values - zh) > required_value                # :1795
+    try:                                            # the reference returns a Series when z is one (:1795)
+        import pandas as pd
+        if isinstance(z, pd.Series):
+            is_object_point = pd.Series(is_object_point, index=z.index, name=z.name)
+    except ImportError:  # pragma: no cover
+        pass
     obj_np = object_cells.cpu().numpy().astype(bool)
     if not return_extras:
         return Zpro, t, obj_np, is_object_point
     drop_raster = drop.cpu().numpy()
+    r, c = r_d.cpu().numpy(), c_d.cpu().numpy()
     extras = {'above_ground_height': zh - elevation_values, 'drop_raster': drop_raster,
               'when_dropped': drop_raster[np.round(r).astype(int), np.round(c).astype(int)]}
     return Zpro, t, obj_np, is_object_point, extras

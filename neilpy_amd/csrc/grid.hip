@@ -99,6 +99,17 @@ __global__ __launch_bounds__(256) void finalize_kernel(const unsigned long long*
   }
 }
 
+// (col, row) = ~t * (x, y) as fractional pixel coordinates (neilpy.py:1772), no FMA contraction
+__global__ __launch_bounds__(256) void affine_kernel(const double* __restrict__ x, const double* __restrict__ y,
+                                                     long long n, double ia, double ib, double ic, double id, double ie,
+                                                     double jf, double* __restrict__ col, double* __restrict__ row) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const double px = x[i], py = y[i];
+    col[i] = __dadd_rn(__dadd_rn(__dmul_rn(px, ia), __dmul_rn(py, ib)), ic);
+    row[i] = __dadd_rn(__dadd_rn(__dmul_rn(px, id), __dmul_rn(py, ie)), jf);
+  }
+}
+
 int nblocks(long long n, int cap) { return (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, cap)); }
 
 }  // namespace
@@ -126,6 +137,16 @@ int smrf_points_extent_f64(const double* d_x, const double* d_y, int64_t n, doub
     r[2] = std::min(r[2], host[b * 4 + 2]); r[3] = std::max(r[3], host[b * 4 + 3]);
   }
   for (int k = 0; k < 4; ++k) h_out[k] = bad ? NAN : r[k];
+  return SMRF_OK;
+}
+
+int smrf_affine_apply_f64(const double* d_x, const double* d_y, int64_t npts, const double* h_inv, double* d_col,
+                          double* d_row, void* stream) {
+  if (npts < 0 || !h_inv || (npts > 0 && (!d_x || !d_y || !d_col || !d_row))) return smrf_fail(SMRF_E_ARG, "null pointer");
+  if (npts == 0) return SMRF_OK;
+  hipLaunchKernelGGL(affine_kernel, dim3(nblocks(npts, 8192)), dim3(256), 0, (hipStream_t)stream, d_x, d_y,
+                     (long long)npts, h_inv[0], h_inv[1], h_inv[2], h_inv[3], h_inv[4], h_inv[5], d_col, d_row);
+  SMRF_LAUNCH_CHECK();
   return SMRF_OK;
 }
 
