@@ -188,7 +188,7 @@ struct RingCfg {
     return n;
   }
   static constexpr int NEED = NEED_BASE + (D - 2) * 4 * G * E;
-  static constexpr int OCC_REG = NEED <= 64 ? 8 : NEED <= 96 ? 5 : NEED <= 128 ? 4 : NEED <= 168 ? 3 : NEED <= 256 ? 2 : 1;
+  static constexpr int OCC_REG = NEED <= 64 ? 8 : NEED <= 96 ? 5 : NEED <= 128 ? 4 : NEED <= 168 ? 3 : NEED <= 264 ? 2 : 1;
   static constexpr int WAVES = TW / 64;                  // waves per workgroup
   static constexpr int WG_LDS = (int)(160 * 1024 / LDS_BYTES) < 1 ? 1 : (int)(160 * 1024 / LDS_BYTES);
   static constexpr int OCC_LDS = WG_LDS * WAVES / 4 < 1 ? 1 : WG_LDS * WAVES / 4;
@@ -399,18 +399,27 @@ void ring_kernel(const DiskArgs<T> a) {
     load_last(yy0);
     SMRF_STAMP(3);                                         // issue of next loads
 
-    // (2) base level JB from level 0: 2^JB - 1 independent reads per cell
+    // (2) base level JB from level 0: 2^JB - 1 independent reads per cell.  All reads of the
+    //     batch are issued first (asm ds_read_b64: hipcc would fuse them into half-rate
+    //     ds_read2_b64), then one wait, then the min/max and the writes.
+    constexpr int NA = (1 << JB) - 1;
+    const unsigned lds_l = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(L + tid);
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const T2* L0 = L + (p * NLEV + par) * WP;
-      T2* LB = L + (p * NLEV + SB) * WP;
+    for (int i = 0; i < NPOS; ++i) {
+      if (i < NPOS - 1 || has_last) {
+        T2 na[NP][NA];
 #pragma unroll
-      for (int i = 0; i < NPOS; ++i) {
-        if (i < NPOS - 1 || has_last) {
-          const int pos = tid + i * TW;
-          T2 n[(1 << JB) - 1];
+        for (int p = 0; p < NP; ++p) {
+          const unsigned ad = lds_l + ((p * NLEV + par) * WP + i * TW) * (unsigned)sizeof(T2);
+          [&]<int... Kk>(std::integer_sequence<int, Kk...>) {
+            ((na[p][Kk] = lds_read2<(Kk + 1) * (int)sizeof(T2)>(ad, T())), ...);
+          }(std::make_integer_sequence<int, NA>{});
+        }
+        lds_wait<0>();
+        const int pos = tid + i * TW;
 #pragma unroll
-          for (int k = 1; k < (1 << JB); ++k) n[k - 1] = L0[pos + k];
+        for (int p = 0; p < NP; ++p) {
+          const T2* n = na[p];
           T2 m = v[p][i];
           if constexpr (JB == 1) { m.x = op2<DIL>(m.x, n[0].x); m.y = op2<DIL>(m.y, n[0].y); }
           if constexpr (JB >= 2) {
@@ -422,8 +431,9 @@ void ring_kernel(const DiskArgs<T> a) {
             m.x = op3<DIL>(m.x, n[5].x, n[6].x); m.y = op3<DIL>(m.y, n[5].y, n[6].y);
           }
           v[p][i] = m;
-          LB[pos] = m;
+          L[(p * NLEV + SB) * WP + pos] = m;
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     SMRF_STAMP(4);                                         // base level
@@ -432,16 +442,25 @@ void ring_kernel(const DiskArgs<T> a) {
     // (3) levels JB+1 .. J from the base level: cells pos + k * 2^JB, k < 2^(J-JB)
     if constexpr (J > JB) {
       constexpr int NB = (1 << (J - JB)) - 1;
+      constexpr int PG = (NP * NB * C::E > 16) ? 1 : NP;        // pairs whose reads are in flight together
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        const T2* LB = L + (p * NLEV + SB) * WP;
+      for (int i = 0; i < NPOS; ++i) {
+        if (i < NPOS - 1 || has_last) {
+         const int pos = tid + i * TW;
 #pragma unroll
-        for (int i = 0; i < NPOS; ++i) {
-          if (i < NPOS - 1 || has_last) {
-            const int pos = tid + i * TW;
-            T2 n[NB];
+         for (int p0 = 0; p0 < NP; p0 += PG) {
+          T2 nb[PG][NB];
 #pragma unroll
-            for (int k = 1; k <= NB; ++k) n[k - 1] = LB[pos + (k << JB)];
+          for (int p = p0; p < p0 + PG; ++p) {
+            const unsigned ad = lds_l + ((p * NLEV + SB) * WP + i * TW) * (unsigned)sizeof(T2);
+            [&]<int... Kk>(std::integer_sequence<int, Kk...>) {
+              ((nb[p - p0][Kk] = lds_read2<((Kk + 1) << JB) * (int)sizeof(T2)>(ad, T())), ...);
+            }(std::make_integer_sequence<int, NB>{});
+          }
+          lds_wait<0>();
+#pragma unroll
+          for (int p = p0; p < p0 + PG; ++p) {
+            const T2* n = nb[p - p0];
             T2 m = v[p][i];
             [&]<int... JJ>(std::integer_sequence<int, JJ...>) {
               (([&] {
@@ -461,6 +480,8 @@ void ring_kernel(const DiskArgs<T> a) {
                }()), ...);
             }(std::make_integer_sequence<int, J - JB>{});
           }
+          __builtin_amdgcn_sched_barrier(0);
+         }
         }
       }
       SMRF_STAMP(6);                                       // higher levels

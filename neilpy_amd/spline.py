@@ -8,6 +8,8 @@ Per axis that is an m x m collocation system with two sub- and two super-diagona
 builds the knots and the banded LU factors of that system (1-D, float64, on the host - O(m));
 the 2-D solves and the evaluation at the points run on the GPU (csrc/spline.hip).
 """
+import functools
+
 import numpy as np
 
 __all__ = ["knots", "bspline_basis", "collocation_bands", "banded_lu", "axis_factors"]
@@ -40,23 +42,35 @@ def bspline_basis(t, l, x):
 
 
 def collocation_bands(x):
-    """Bands of the collocation matrix A[i, j] = B_j(x_i): array (5, m), band b holds A[i, i+b-2]."""
+    """Bands of the collocation matrix A[i, j] = B_j(x_i): array (5, m), band b holds A[i, i+b-2].
+
+    Vectorised over the sites: the same fpbspl recurrence as :func:`bspline_basis`, on arrays."""
     x = np.asarray(x, dtype=np.float64)
     m = x.size
     t = knots(x)
     n = t.size
+    # interval l with t[l] <= x < t[l+1], 3 <= l <= n-5 (the last interval also takes x = t[n-4])
+    l = np.clip(np.searchsorted(t, x, side="right") - 1, 3, n - 5)
+    h = np.zeros((4, m))
+    hh = np.zeros((4, m))
+    h[0] = 1.0
+    for j in range(1, 4):
+        hh[:j] = h[:j]
+        h[0] = 0.0
+        for i in range(j):
+            li = l + i + 1
+            lj = li - j
+            f = hh[i] / (t[li] - t[lj])
+            h[i] = h[i] + f * (t[li] - x)
+            h[i + 1] = f * (x - t[lj])
     bands = np.zeros((5, m))
-    l = 3
-    for i in range(m):
-        while l < n - 5 and x[i] >= t[l + 1]:
-            l += 1
-        h = bspline_basis(t, l, x[i])
-        for q in range(4):
-            j = l - 3 + q
-            if h[q] != 0.0:
-                b = j - i + 2
-                assert 0 <= b < 5, "collocation matrix is not penta-diagonal"
-                bands[b, i] = h[q]
+    rows = np.arange(m)
+    for q in range(4):
+        b = (l - 3 + q) - rows + 2                    # band of column l-3+q in row i
+        nz = h[q] != 0.0
+        if np.any(nz & ((b < 0) | (b > 4))):
+            raise AssertionError("collocation matrix is not penta-diagonal")
+        bands[b[nz], rows[nz]] = h[q][nz]
     return bands
 
 
@@ -94,6 +108,7 @@ def banded_lu(bands):
     return np.stack([l2, l1, d, u1, u2])
 
 
+@functools.lru_cache(maxsize=16)
 def axis_factors(m):
     """(knots, LU bands) for the sites 0.5, 1.5, ..., m - 0.5 (pixel centres, neilpy.py:1768-1769)."""
     x = np.arange(0.5, m + .5)

@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--n", type=int, default=16384)
+    ap.add_argument("--size", "--n", dest="n", type=int, default=16384)
     ap.add_argument("--radii", default="1,8,18,32,50")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--dilate", action="store_true")
