@@ -32,6 +32,11 @@
 #ifndef SMRF_RING_DEPTH
 #define SMRF_RING_DEPTH(need) 2   /* measured: a third group in flight gains nothing (lookups are not the exposed latency) */
 #endif
+// lookups per pipelined group: 4, or 2 where the 16 VGPRs saved keep a third wave per SIMD
+// (ring + window registers between 116 and 132 in fp32)
+#ifndef SMRF_RING_G
+#define SMRF_RING_G(ringregs) (((ringregs) > 116 && (ringregs) <= 132) ? 2 : 4)
+#endif
 #ifndef SMRF_FORCE_OCC
 #define SMRF_OCC_OVERRIDE(...) __VA_ARGS__
 #else
@@ -177,10 +182,10 @@ struct RingCfg {
   }
   static constexpr int NLEV = slot_of(J) + 1;
   static constexpr size_t LDS_BYTES = ((size_t)NP * NLEV * WP + PAD) * 2 * sizeof(T);
-  static constexpr int G = 4;                            // window lookups per pipelined group
+  static constexpr int G = SMRF_RING_G(E * (2 * R + 2 * S::K));   // window lookups per pipelined group
   static constexpr int NG = (S::K - 1 + G - 1) / G;      // groups for k = 1..K-1
   static constexpr int gsize(int g) { int n = S::K - 1 - g * G; return n < 0 ? 0 : (n > G ? G : n); }
-  static constexpr int NEED_BASE = E * (2 * R + 2 * S::K + 36) + 16;   // measured VGPR demand at D = 2
+  static constexpr int NEED_BASE = E * (2 * R + 2 * S::K + 20 + 4 * G) + 16;   // measured VGPR demand at D = 2
   static constexpr int D = SMRF_RING_DEPTH(NEED_BASE);   // lookup groups kept in flight
   static constexpr int inflight_after(int g) {           // lookups of groups g+1 .. g+D-1
     int n = 0;
