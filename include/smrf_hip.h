@@ -166,6 +166,30 @@ SMRF_API int smrf_springs_lsqr_f64(double* d_A, int rows, int cols, double atol,
                           int64_t* h_n_unknown, void* d_workspace, size_t workspace_bytes,
                           void* stream);
 
+/* Row-band form of the same solver for rasters sharded over several GPUs.  The band
+ * holds rows_local x cols cells of d_A_band.  The workspace keeps every plane with one halo row
+ * above and one below; smrf_springs_band_layout() gives the byte offsets the host needs to
+ * exchange halo rows and to all-reduce the one scalar between phases:
+ *   h_out[0] v plane, h_out[1] uv plane (rows_local + 2 rows of cols doubles, row 0 = halo above),
+ *   h_out[2] hole plane (rows_local + 2 rows of cols bytes), h_out[3] cols doubles = raster row
+ *   below the band, h_out[4] one double = the phase's local sum, h_out[5] total bytes.
+ * Phases (in order; "<- X" = what the host must have delivered before the phase):
+ *   0 mask+count | 1 rhs <- hole halo below, A row below, all-reduced count | 2 |b| <- all-reduce
+ *   3 v = S^T u - beta v <- uv halo above | 4 first alfa, w <- all-reduce
+ *   loop: 5 u = S v - alfa u <- v halo below | 6 beta <- all-reduce | 3 | 7 alfa + rotation <- all-reduce
+ *         8 x, w update | 9 stopping tests <- all-reduce
+ *   10 scatter the solution into d_A_band.
+ * neilpy_amd/sharded.py drives it over torch.distributed (RCCL). */
+SMRF_API size_t smrf_springs_band_workspace_bytes(int rows_local, int cols);
+SMRF_API int smrf_springs_band_layout(int rows_local, int cols, int64_t* h_out);
+SMRF_API int smrf_springs_band_begin(int rows_local, int cols, double atol, double btol, double conlim,
+                            int64_t iter_lim, void* d_workspace, size_t workspace_bytes,
+                            void* stream);
+SMRF_API int smrf_springs_band_phase(int phase, double* d_A_band, int rows_local, int cols, int has_above,
+                            int has_below, void* d_workspace, size_t workspace_bytes, void* stream);
+SMRF_API int smrf_springs_band_status(const void* d_workspace, int rows_local, int cols, int* h_istop,
+                             int64_t* h_itn, int64_t* h_n_unknown, int* h_done, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * smrf tail
  * ------------------------------------------------------------------------------------------ */

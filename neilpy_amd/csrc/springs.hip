@@ -13,8 +13,12 @@
 //   - u and v are stored UNSCALED with their scale (1/beta, 1/alfa) kept as a scalar and applied
 //     on every read, which reproduces scipy's "u = (1/beta) * u" rounding exactly and makes every
 //     kernel in-place safe (a thread only writes the entries it owns).
-// The scalar recurrence runs in one-lane kernels between the vector kernels, so an iteration is
-// six launches and no host round trip; the host polls the stop flag every few iterations.
+// The scalar recurrence runs in one-lane kernels between the vector kernels, so an iteration needs
+// no host round trip; the host polls the stop flag every few iterations.
+// Row-band form: every kernel works on rows [0, rows) of a band whose planes carry one halo row
+// above and one below (v and the hole mask below, uv above); the phase entry point lets the host
+// exchange those rows and all-reduce the one scalar between phases (neilpy_amd/sharded.py).  The
+// single-device solver is the same kernels on a band that is the whole raster.
 // Reductions are two-stage with a fixed tree (no float atomics): results are reproducible.
 // HBM-bound: per iteration about 3 plane reads + 2 plane writes of each of u (2 planes), v, w, x.
 #include <algorithm>
@@ -35,6 +39,18 @@ struct Sc {
   int istop, done, beta_pos, pad;
 };
 
+// One row band of the raster.  Plane pointers address the first OWN row; row -1 and row `rows` are
+// halo rows (allocated always, meaningful only where has_above / has_below).
+struct Band {
+  double *x, *v, *w, *uh, *uv;
+  uint8_t* hole;
+  double* abelow;     // the raster row just below the band (has_below)
+  double* part;       // MAXB block partials
+  double* red;        // red[0]: the phase's sum (local; the host all-reduces it between phases)
+  Sc* sc;
+  int rows, cols, has_above, has_below;
+};
+
 __device__ __forceinline__ double block_sum(double s, double* red) {
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
   const int w = threadIdx.x >> 6;
@@ -47,295 +63,367 @@ __device__ __forceinline__ double block_sum(double s, double* red) {
 
 __device__ __forceinline__ bool stopped(const Sc* sc) { return sc->done != 0 || sc->istop != 0; }
 
-// ---- setup ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mask_kernel(const double* __restrict__ A, uint8_t* __restrict__ hole,
-                                                   long long n, double* __restrict__ part) {
+// block partials -> red[0]
+__global__ __launch_bounds__(256) void reduce_kernel(const double* __restrict__ part, int nb, double* __restrict__ out) {
   __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256) s += part[i];
+  const double t = block_sum(s, red);
+  if (threadIdx.x == 0) out[0] = t;
+}
+
+// ---- setup ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_kernel(const double* __restrict__ A, const Band b) {
+  __shared__ double red[4];
+  const long long n = (long long)b.rows * b.cols;
   double c = 0.0;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const double a = A[i];
     const bool h = a != a;
-    hole[i] = h;
+    b.hole[i] = h;
     c += h ? 1.0 : 0.0;
   }
   const double t = block_sum(c, red);
-  if (threadIdx.x == 0) part[blockIdx.x] = t;
+  if (threadIdx.x == 0) b.part[blockIdx.x] = t;
 }
 
 // rhs = -S_known @ A_known  (neilpy.py:1263): on an active edge, K[hi] - K[lo] with K = 0 at holes
-__global__ __launch_bounds__(256) void rhs_kernel(const double* __restrict__ A, const uint8_t* __restrict__ hole,
-                                                  double* __restrict__ uh, double* __restrict__ uv, int rows,
-                                                  int cols, double* __restrict__ x, double* __restrict__ v,
-                                                  double* __restrict__ w, double* __restrict__ part) {
+__global__ __launch_bounds__(256) void rhs_kernel(const double* __restrict__ A, const Band b) {
   __shared__ double red[4];
+  const int rows = b.rows, cols = b.cols;
   const long long n = (long long)rows * cols;
   double s = 0.0;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
-    const bool h0 = hole[i];
+    const bool h0 = b.hole[i];
     const double k0 = h0 ? 0.0 : A[i];
     double eh = 0.0, ev = 0.0;
     if (c + 1 < cols) {
-      const bool h1 = hole[i + 1];
+      const bool h1 = b.hole[i + 1];
       if (h0 | h1) eh = (h1 ? 0.0 : A[i + 1]) - k0;
     }
-    if (r + 1 < rows) {
-      const bool h1 = hole[i + cols];
-      if (h0 | h1) ev = (h1 ? 0.0 : A[i + cols]) - k0;
+    if (r + 1 < rows || b.has_below) {
+      const bool h1 = b.hole[i + cols];
+      const double a1 = r + 1 < rows ? A[i + cols] : b.abelow[c];
+      if (h0 | h1) ev = (h1 ? 0.0 : a1) - k0;
     }
-    uh[i] = eh;
-    uv[i] = ev;
-    x[i] = 0.0;
-    v[i] = 0.0;
-    w[i] = 0.0;
+    b.uh[i] = eh;
+    b.uv[i] = ev;
+    b.x[i] = 0.0;
+    b.v[i] = 0.0;
+    b.w[i] = 0.0;
     s += eh * eh;
     s += ev * ev;
   }
   const double t = block_sum(s, red);
-  if (threadIdx.x == 0) part[blockIdx.x] = t;
+  if (threadIdx.x == 0) b.part[blockIdx.x] = t;
 }
 
-__device__ __forceinline__ double final_sum(const double* part, int nb, double* red) {
-  double s = 0.0;
-  for (int i = threadIdx.x; i < nb; i += 256) s += part[i];
-  return block_sum(s, red);
+__global__ void s_count(const Band b) {
+  Sc* sc = b.sc;
+  sc->nunk = (long long)b.red[0];
+  if (sc->iter_lim < 0) sc->iter_lim = 2 * sc->nunk;
+  if (sc->nunk == 0) sc->done = 1;
 }
 
-__global__ __launch_bounds__(256) void s_count(const double* part, int nb, Sc* sc) {
-  __shared__ double red[4];
-  const double t = final_sum(part, nb, red);
-  if (threadIdx.x == 0) {
-    sc->nunk = (long long)t;
-    if (sc->iter_lim < 0) sc->iter_lim = 2 * sc->nunk;
-    if (sc->nunk == 0) sc->done = 1;
-  }
-}
-
-__global__ __launch_bounds__(256) void s_bnorm(const double* part, int nb, Sc* sc) {
-  __shared__ double red[4];
-  const double t = final_sum(part, nb, red);
-  if (threadIdx.x == 0) {
-    const double b = sqrt(t);
-    sc->bnorm = b;
-    sc->beta = b;
-    sc->beta_pos = b > 0;
-    sc->inv_beta = b > 0 ? 1 / b : 1.0;
-    sc->alfa = 0.0;
-    sc->inv_alfa = 1.0;
-  }
+__global__ void s_bnorm(const Band b) {
+  Sc* sc = b.sc;
+  const double bn = sqrt(b.red[0]);
+  sc->bnorm = bn;
+  sc->beta = bn;
+  sc->beta_pos = bn > 0;
+  sc->inv_beta = bn > 0 ? 1 / bn : 1.0;
+  sc->alfa = 0.0;
+  sc->inv_alfa = 1.0;
 }
 
 // ---- v = S^T u_s - beta * v_s  (u_s = inv_beta*u, v_s = inv_alfa*v), partial |v|^2 -----------
-__global__ __launch_bounds__(256) void atu_kernel(const double* __restrict__ uh, const double* __restrict__ uv,
-                                                  const uint8_t* __restrict__ hole, double* __restrict__ v,
-                                                  int rows, int cols, const Sc* __restrict__ sc,
-                                                  double* __restrict__ part) {
+__global__ __launch_bounds__(256) void atu_kernel(const Band b) {
   __shared__ double red[4];
+  const Sc* sc = b.sc;
   if (stopped(sc) || !sc->beta_pos) return;
   const double ib = sc->inv_beta, ia = sc->inv_alfa, beta = sc->beta;
+  const int rows = b.rows, cols = b.cols;
   const long long n = (long long)rows * cols;
   double s = 0.0;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    if (!hole[i]) continue;
+    if (!b.hole[i]) continue;
     const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
     double y = 0.0;
-    if (r > 0) y = y - ib * uv[i - cols];
-    if (c > 0) y = y - ib * uh[i - 1];
-    if (c + 1 < cols) y = y + ib * uh[i];
-    if (r + 1 < rows) y = y + ib * uv[i];
-    const double nv = y - beta * (ia * v[i]);
-    v[i] = nv;
+    if (r > 0 || b.has_above) y = y - ib * b.uv[i - cols];
+    if (c > 0) y = y - ib * b.uh[i - 1];
+    if (c + 1 < cols) y = y + ib * b.uh[i];
+    if (r + 1 < rows || b.has_below) y = y + ib * b.uv[i];
+    const double nv = y - beta * (ia * b.v[i]);
+    b.v[i] = nv;
     s += nv * nv;
   }
   const double t = block_sum(s, red);
-  if (threadIdx.x == 0) part[blockIdx.x] = t;
+  if (threadIdx.x == 0) b.part[blockIdx.x] = t;
 }
 
-__global__ __launch_bounds__(256) void s_init_alfa(const double* part, int nb, Sc* sc) {
-  __shared__ double red[4];
+__global__ void s_init_alfa(const Band b) {
+  Sc* sc = b.sc;
   if (sc->done) return;
-  double t = 0.0;
-  if (sc->beta_pos) t = final_sum(part, nb, red);
-  if (threadIdx.x == 0) {
-    const double a = sc->beta_pos ? sqrt(t) : 0.0;
-    sc->alfa = a;
-    sc->inv_alfa = a > 0 ? 1 / a : 1.0;
-    sc->rhobar = a;
-    sc->phibar = sc->beta;
-    if (a * sc->beta == 0) sc->done = 1;      // arnorm == 0: x = 0 is the answer (lsqr.py:386-390)
-  }
+  const double a = sc->beta_pos ? sqrt(b.red[0]) : 0.0;
+  sc->alfa = a;
+  sc->inv_alfa = a > 0 ? 1 / a : 1.0;
+  sc->rhobar = a;
+  sc->phibar = sc->beta;
+  if (a * sc->beta == 0) sc->done = 1;      // arnorm == 0: x = 0 is the answer (lsqr.py:386-390)
 }
 
-__global__ __launch_bounds__(256) void w_init_kernel(const double* __restrict__ v, double* __restrict__ w,
-                                                     long long n, const Sc* __restrict__ sc) {
-  if (sc->done) return;
-  const double ia = sc->inv_alfa;
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) w[i] = ia * v[i];
+__global__ __launch_bounds__(256) void w_init_kernel(const Band b) {
+  if (b.sc->done) return;
+  const double ia = b.sc->inv_alfa;
+  const long long n = (long long)b.rows * b.cols;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) b.w[i] = ia * b.v[i];
 }
 
 // ---- u = S v_s - alfa * u_s, partial |u|^2 ---------------------------------------------------
-__global__ __launch_bounds__(256) void av_kernel(double* __restrict__ uh, double* __restrict__ uv,
-                                                 const uint8_t* __restrict__ hole, const double* __restrict__ v,
-                                                 int rows, int cols, const Sc* __restrict__ sc,
-                                                 double* __restrict__ part) {
+__global__ __launch_bounds__(256) void av_kernel(const Band b) {
   __shared__ double red[4];
+  const Sc* sc = b.sc;
   if (stopped(sc)) return;
   const double ib = sc->inv_beta, ia = sc->inv_alfa, alfa = sc->alfa;
+  const int rows = b.rows, cols = b.cols;
   const long long n = (long long)rows * cols;
   double s = 0.0;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
-    const bool h0 = hole[i];
-    const double v0 = ia * v[i];
+    const bool h0 = b.hole[i];
+    const double v0 = ia * b.v[i];
     if (c + 1 < cols) {
-      if (h0 | hole[i + 1]) {
-        const double nu = (v0 - ia * v[i + 1]) - alfa * (ib * uh[i]);
-        uh[i] = nu;
+      if (h0 | b.hole[i + 1]) {
+        const double nu = (v0 - ia * b.v[i + 1]) - alfa * (ib * b.uh[i]);
+        b.uh[i] = nu;
         s += nu * nu;
       }
     }
-    if (r + 1 < rows) {
-      if (h0 | hole[i + cols]) {
-        const double nu = (v0 - ia * v[i + cols]) - alfa * (ib * uv[i]);
-        uv[i] = nu;
+    if (r + 1 < rows || b.has_below) {
+      if (h0 | b.hole[i + cols]) {
+        const double nu = (v0 - ia * b.v[i + cols]) - alfa * (ib * b.uv[i]);
+        b.uv[i] = nu;
         s += nu * nu;
       }
     }
   }
   const double t = block_sum(s, red);
-  if (threadIdx.x == 0) part[blockIdx.x] = t;
+  if (threadIdx.x == 0) b.part[blockIdx.x] = t;
 }
 
-__global__ __launch_bounds__(256) void s_beta(const double* part, int nb, Sc* sc) {
-  __shared__ double red[4];
+__global__ void s_beta(const Band b) {
+  Sc* sc = b.sc;
   if (stopped(sc)) return;
-  const double t = final_sum(part, nb, red);
-  if (threadIdx.x == 0) {
-    const double b = sqrt(t);
-    sc->beta = b;
-    sc->beta_pos = b > 0;
-    if (b > 0) {
-      sc->inv_beta = 1 / b;
-      sc->anorm = sqrt(sc->anorm * sc->anorm + sc->alfa * sc->alfa + b * b);
-    } else {
-      sc->inv_beta = 1.0;   // scipy leaves u unscaled when beta == 0
-    }
+  const double bt = sqrt(b.red[0]);
+  sc->beta = bt;
+  sc->beta_pos = bt > 0;
+  if (bt > 0) {
+    sc->inv_beta = 1 / bt;
+    sc->anorm = sqrt(sc->anorm * sc->anorm + sc->alfa * sc->alfa + bt * bt);
+  } else {
+    sc->inv_beta = 1.0;   // scipy leaves u unscaled when beta == 0
   }
 }
 
 __device__ __forceinline__ double sgn(double a) { return a > 0 ? 1.0 : (a < 0 ? -1.0 : 0.0); }
 
-__global__ __launch_bounds__(256) void s_alfa_rot(const double* part, int nb, Sc* sc) {
-  __shared__ double red[4];
+__global__ void s_alfa_rot(const Band bd) {
+  Sc* sc = bd.sc;
   if (stopped(sc)) return;
-  double t = 0.0;
-  if (sc->beta_pos) t = final_sum(part, nb, red);
-  if (threadIdx.x == 0) {
-    if (sc->beta_pos) {
-      const double a = sqrt(t);
-      sc->alfa = a;
-      sc->inv_alfa = a > 0 ? 1 / a : 1.0;
-    }
-    const double alfa = sc->alfa, beta = sc->beta;
-    // cs, sn, rho = _sym_ortho(rhobar, beta)   (lsqr.py:62-94)
-    const double a = sc->rhobar, b = beta;
-    double cs, sn, rho;
-    if (b == 0) { cs = sgn(a); sn = 0; rho = fabs(a); }
-    else if (a == 0) { cs = 0; sn = sgn(b); rho = fabs(b); }
-    else if (fabs(b) > fabs(a)) { const double tau = a / b; sn = sgn(b) / sqrt(1 + tau * tau); cs = sn * tau; rho = b / sn; }
-    else { const double tau = b / a; cs = sgn(a) / sqrt(1 + tau * tau); sn = cs * tau; rho = a / cs; }
-    const double theta = sn * alfa;
-    sc->rhobar = -cs * alfa;
-    const double phi = cs * sc->phibar;
-    sc->phibar = sn * sc->phibar;
-    const double tau = sn * phi;
-    sc->t1 = phi / rho;
-    sc->t2 = -theta / rho;
-    sc->inv_rho = 1 / rho;
-    // the norm(x) estimate (lsqr.py:474-483)
-    const double delta = sc->sn2 * rho;
-    const double gambar = -sc->cs2 * rho;
-    const double rhs = phi - delta * sc->z;
-    const double zbar = rhs / gambar;
-    const double xnorm = sqrt(sc->xxnorm + zbar * zbar);
-    const double gamma = sqrt(gambar * gambar + theta * theta);
-    sc->cs2 = gambar / gamma;
-    sc->sn2 = theta / gamma;
-    sc->z = rhs / gamma;
-    sc->xxnorm = sc->xxnorm + sc->z * sc->z;
-    sc->xnorm = xnorm;   // for s_tests
-    sc->tau = tau;
+  if (sc->beta_pos) {
+    const double a = sqrt(bd.red[0]);
+    sc->alfa = a;
+    sc->inv_alfa = a > 0 ? 1 / a : 1.0;
   }
+  const double alfa = sc->alfa, beta = sc->beta;
+  // cs, sn, rho = _sym_ortho(rhobar, beta)   (lsqr.py:62-94)
+  const double a = sc->rhobar, b = beta;
+  double cs, sn, rho;
+  if (b == 0) { cs = sgn(a); sn = 0; rho = fabs(a); }
+  else if (a == 0) { cs = 0; sn = sgn(b); rho = fabs(b); }
+  else if (fabs(b) > fabs(a)) { const double tau = a / b; sn = sgn(b) / sqrt(1 + tau * tau); cs = sn * tau; rho = b / sn; }
+  else { const double tau = b / a; cs = sgn(a) / sqrt(1 + tau * tau); sn = cs * tau; rho = a / cs; }
+  const double theta = sn * alfa;
+  sc->rhobar = -cs * alfa;
+  const double phi = cs * sc->phibar;
+  sc->phibar = sn * sc->phibar;
+  const double tau = sn * phi;
+  sc->t1 = phi / rho;
+  sc->t2 = -theta / rho;
+  sc->inv_rho = 1 / rho;
+  // the norm(x) estimate (lsqr.py:474-483)
+  const double delta = sc->sn2 * rho;
+  const double gambar = -sc->cs2 * rho;
+  const double rhs = phi - delta * sc->z;
+  const double zbar = rhs / gambar;
+  const double xnorm = sqrt(sc->xxnorm + zbar * zbar);
+  const double gamma = sqrt(gambar * gambar + theta * theta);
+  sc->cs2 = gambar / gamma;
+  sc->sn2 = theta / gamma;
+  sc->z = rhs / gamma;
+  sc->xxnorm = sc->xxnorm + sc->z * sc->z;
+  sc->xnorm = xnorm;   // for s_tests
+  sc->tau = tau;
 }
 
 // ---- x += t1*w ; w = v_s + t2*w ; partial |w/rho|^2 ------------------------------------------
-__global__ __launch_bounds__(256) void xw_kernel(double* __restrict__ x, double* __restrict__ w,
-                                                 const double* __restrict__ v, const uint8_t* __restrict__ hole,
-                                                 long long n, const Sc* __restrict__ sc, double* __restrict__ part) {
+__global__ __launch_bounds__(256) void xw_kernel(const Band b) {
   __shared__ double red[4];
+  const Sc* sc = b.sc;
   if (stopped(sc)) return;
   const double t1 = sc->t1, t2 = sc->t2, ir = sc->inv_rho, ia = sc->inv_alfa;
+  const long long n = (long long)b.rows * b.cols;
   double s = 0.0;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    if (!hole[i]) continue;
-    const double ws = w[i];
+    if (!b.hole[i]) continue;
+    const double ws = b.w[i];
     const double dk = ir * ws;
-    x[i] = x[i] + t1 * ws;
-    w[i] = ia * v[i] + t2 * ws;
+    b.x[i] = b.x[i] + t1 * ws;
+    b.w[i] = ia * b.v[i] + t2 * ws;
     s += dk * dk;
   }
   const double t = block_sum(s, red);
-  if (threadIdx.x == 0) part[blockIdx.x] = t;
+  if (threadIdx.x == 0) b.part[blockIdx.x] = t;
 }
 
-__global__ __launch_bounds__(256) void s_tests(const double* part, int nb, Sc* sc) {
-  __shared__ double red[4];
+__global__ void s_tests(const Band b) {
+  Sc* sc = b.sc;
   if (stopped(sc)) return;
-  const double t = final_sum(part, nb, red);
-  if (threadIdx.x == 0) {
-    const double EPS = 2.220446049250313e-16;
-    const double xnorm = sc->xnorm, tau = sc->tau;
-    const double nd = sqrt(t);
-    sc->ddnorm = sc->ddnorm + nd * nd;
-    sc->itn += 1;
-    const double anorm = sc->anorm, bnorm = sc->bnorm;
-    const double acond = anorm * sqrt(sc->ddnorm);
-    const double rnorm = sqrt(sc->phibar * sc->phibar);
-    const double arnorm = sc->alfa * fabs(tau);
-    const double test1 = rnorm / bnorm;
-    const double test2 = arnorm / (anorm * rnorm + EPS);
-    const double test3 = 1 / (acond + EPS);
-    const double t1 = test1 / (1 + anorm * xnorm / bnorm);
-    const double rtol = sc->btol + sc->atol * anorm * xnorm / bnorm;
-    int istop = 0;
-    if (sc->itn >= sc->iter_lim) istop = 7;
-    if (1 + test3 <= 1) istop = 6;
-    if (1 + test2 <= 1) istop = 5;
-    if (1 + t1 <= 1) istop = 4;
-    if (test3 <= sc->ctol) istop = 3;
-    if (test2 <= sc->atol) istop = 2;
-    if (test1 <= rtol) istop = 1;
-    sc->istop = istop;
-  }
+  const double EPS = 2.220446049250313e-16;
+  const double xnorm = sc->xnorm, tau = sc->tau;
+  const double nd = sqrt(b.red[0]);
+  sc->ddnorm = sc->ddnorm + nd * nd;
+  sc->itn += 1;
+  const double anorm = sc->anorm, bnorm = sc->bnorm;
+  const double acond = anorm * sqrt(sc->ddnorm);
+  const double rnorm = sqrt(sc->phibar * sc->phibar);
+  const double arnorm = sc->alfa * fabs(tau);
+  const double test1 = rnorm / bnorm;
+  const double test2 = arnorm / (anorm * rnorm + EPS);
+  const double test3 = 1 / (acond + EPS);
+  const double t1 = test1 / (1 + anorm * xnorm / bnorm);
+  const double rtol = sc->btol + sc->atol * anorm * xnorm / bnorm;
+  int istop = 0;
+  if (sc->itn >= sc->iter_lim) istop = 7;
+  if (1 + test3 <= 1) istop = 6;
+  if (1 + test2 <= 1) istop = 5;
+  if (1 + t1 <= 1) istop = 4;
+  if (test3 <= sc->ctol) istop = 3;
+  if (test2 <= sc->atol) istop = 2;
+  if (test1 <= rtol) istop = 1;
+  sc->istop = istop;
 }
 
-__global__ __launch_bounds__(256) void scatter_kernel(double* __restrict__ A, const double* __restrict__ x,
-                                                      const uint8_t* __restrict__ hole, long long n) {
+__global__ __launch_bounds__(256) void scatter_kernel(double* __restrict__ A, const Band b) {
+  const long long n = (long long)b.rows * b.cols;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-    if (hole[i]) A[i] = x[i];
+    if (b.hole[i]) A[i] = b.x[i];
 }
 
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// workspace carve-up shared by the single-device solver and the band phases.
+// offsets (bytes): x, v, w, uh, uv (first ALLOCATED row = halo above), hole, abelow, part, red, sc
+struct Layout {
+  size_t plane, x, v, w, uh, uv, hole, abelow, part, red, sc, total;
+};
+Layout layout_of(int rows, int cols) {
+  Layout L;
+  const size_t n2 = (size_t)(rows + 2) * (size_t)cols;
+  L.plane = align_up(n2 * sizeof(double));
+  size_t o = 0;
+  L.x = o; o += L.plane;
+  L.v = o; o += L.plane;
+  L.w = o; o += L.plane;
+  L.uh = o; o += L.plane;
+  L.uv = o; o += L.plane;
+  L.hole = o; o += align_up(n2);
+  L.abelow = o; o += align_up((size_t)cols * sizeof(double));
+  L.part = o; o += align_up(MAXB * sizeof(double));
+  L.red = o; o += 256;
+  L.sc = o; o += align_up(sizeof(Sc));
+  L.total = o;
+  return L;
+}
+Band band_of(void* ws, int rows, int cols, int has_above, int has_below) {
+  const Layout L = layout_of(rows, cols);
+  char* p = (char*)ws;
+  Band b;
+  b.x = (double*)(p + L.x) + cols;
+  b.v = (double*)(p + L.v) + cols;
+  b.w = (double*)(p + L.w) + cols;
+  b.uh = (double*)(p + L.uh) + cols;
+  b.uv = (double*)(p + L.uv) + cols;
+  b.hole = (uint8_t*)(p + L.hole) + cols;
+  b.abelow = (double*)(p + L.abelow);
+  b.part = (double*)(p + L.part);
+  b.red = (double*)(p + L.red);
+  b.sc = (Sc*)(p + L.sc);
+  b.rows = rows; b.cols = cols; b.has_above = has_above; b.has_below = has_below;
+  return b;
+}
+int nblocks(const Band& b) {
+  const long long n = (long long)b.rows * b.cols;
+  return (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, MAXB));
+}
+
+enum Phase {
+  PH_MASK = 0,      // hole mask of own rows, red[0] = local unknown count
+  PH_RHS = 1,       // (after hole/A halo + count all-reduce) rhs, red[0] = local |b|^2
+  PH_BNORM = 2,     // (after all-reduce) beta = |b|
+  PH_ATU = 3,       // (after uv halo)  v = S^T u - beta v, red[0] = local |v|^2
+  PH_INIT_ALFA = 4, // (after all-reduce) alfa, w = v
+  PH_AV = 5,        // (after v halo)   u = S v - alfa u, red[0] = local |u|^2
+  PH_BETA = 6,      // (after all-reduce)
+  PH_ALFA_ROT = 7,  // (after PH_ATU + all-reduce) alfa, plane rotation
+  PH_XW = 8,        // x, w update, red[0] = local |w/rho|^2
+  PH_TESTS = 9,     // (after all-reduce) stopping tests, itn += 1
+  PH_SCATTER = 10,  // A[hole] = x
+};
+
+int run_phase(int phase, double* A, const Band& b, hipStream_t st) {
+  const int nb = nblocks(b);
+  auto reduce = [&]() { hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(256), 0, st, (const double*)b.part, nb, b.red); };
+  switch (phase) {
+    case PH_MASK: hipLaunchKernelGGL(mask_kernel, dim3(nb), dim3(256), 0, st, (const double*)A, b); reduce(); break;
+    case PH_RHS:
+      hipLaunchKernelGGL(s_count, dim3(1), dim3(1), 0, st, b);
+      hipLaunchKernelGGL(rhs_kernel, dim3(nb), dim3(256), 0, st, (const double*)A, b);
+      reduce();
+      break;
+    case PH_BNORM: hipLaunchKernelGGL(s_bnorm, dim3(1), dim3(1), 0, st, b); break;
+    case PH_ATU: hipLaunchKernelGGL(atu_kernel, dim3(nb), dim3(256), 0, st, b); reduce(); break;
+    case PH_INIT_ALFA:
+      hipLaunchKernelGGL(s_init_alfa, dim3(1), dim3(1), 0, st, b);
+      hipLaunchKernelGGL(w_init_kernel, dim3(nb), dim3(256), 0, st, b);
+      break;
+    case PH_AV: hipLaunchKernelGGL(av_kernel, dim3(nb), dim3(256), 0, st, b); reduce(); break;
+    case PH_BETA: hipLaunchKernelGGL(s_beta, dim3(1), dim3(1), 0, st, b); break;
+    case PH_ALFA_ROT: hipLaunchKernelGGL(s_alfa_rot, dim3(1), dim3(1), 0, st, b); break;
+    case PH_XW: hipLaunchKernelGGL(xw_kernel, dim3(nb), dim3(256), 0, st, b); reduce(); break;
+    case PH_TESTS: hipLaunchKernelGGL(s_tests, dim3(1), dim3(1), 0, st, b); break;
+    case PH_SCATTER: hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, st, A, b); break;
+    default: return smrf_fail(SMRF_E_ARG, "unknown springs phase %d", phase);
+  }
+  SMRF_LAUNCH_CHECK();
+  return SMRF_OK;
+}
+
+int init_scalars(const Band& b, double atol, double btol, double conlim, int64_t iter_lim, hipStream_t st) {
+  Sc h{};
+  h.atol = atol; h.btol = btol; h.ctol = conlim > 0 ? 1 / conlim : 0.0;
+  h.cs2 = -1.0; h.iter_lim = iter_lim;
+  SMRF_HIP_CHECK(hipMemcpyAsync(b.sc, &h, sizeof(h), hipMemcpyHostToDevice, st));
+  SMRF_HIP_CHECK(hipStreamSynchronize(st));   // h is a stack object
+  return SMRF_OK;
+}
 
 }  // namespace
 
 extern "C" {
 
-size_t smrf_springs_workspace_bytes(int rows, int cols) {
-  const size_t n = (size_t)rows * (size_t)cols;
-  return 5 * align_up(n * sizeof(double)) + align_up(n) + align_up(MAXB * sizeof(double)) +
-         align_up(sizeof(Sc));
-}
+size_t smrf_springs_workspace_bytes(int rows, int cols) { return layout_of(rows, cols).total; }
 
 int smrf_springs_lsqr_f64(double* d_A, int rows, int cols, double atol, double btol, double conlim,
                           int64_t iter_lim, int* h_istop, int64_t* h_itn, int64_t* h_n_unknown,
@@ -345,60 +433,76 @@ int smrf_springs_lsqr_f64(double* d_A, int rows, int cols, double atol, double b
   if (rows < 1 || cols < 1) return smrf_fail(SMRF_E_ARG, "bad raster size %d x %d", rows, cols);
   if (!d_workspace || workspace_bytes < smrf_springs_workspace_bytes(rows, cols))
     return smrf_fail(SMRF_E_WORKSPACE, "springs workspace too small");
-  const long long n = (long long)rows * cols;
-  char* p = (char*)d_workspace;
-  const size_t pl = align_up((size_t)n * sizeof(double));
-  double* x = (double*)p; p += pl;
-  double* v = (double*)p; p += pl;
-  double* w = (double*)p; p += pl;
-  double* uh = (double*)p; p += pl;
-  double* uv = (double*)p; p += pl;
-  uint8_t* hole = (uint8_t*)p; p += align_up((size_t)n);
-  double* part = (double*)p; p += align_up(MAXB * sizeof(double));
-  Sc* sc = (Sc*)p;
-
-  const int nb = (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, MAXB));
-  Sc h{};
-  h.atol = atol; h.btol = btol; h.ctol = conlim > 0 ? 1 / conlim : 0.0;
-  h.cs2 = -1.0; h.iter_lim = iter_lim;
-  SMRF_HIP_CHECK(hipMemcpyAsync(sc, &h, sizeof(h), hipMemcpyHostToDevice, stream));
-  SMRF_HIP_CHECK(hipStreamSynchronize(stream));   // h is a stack object
-
-  hipLaunchKernelGGL(mask_kernel, dim3(nb), dim3(256), 0, stream, d_A, hole, n, part);
-  hipLaunchKernelGGL(s_count, dim3(1), dim3(256), 0, stream, part, nb, sc);
-  hipLaunchKernelGGL(rhs_kernel, dim3(nb), dim3(256), 0, stream, d_A, hole, uh, uv, rows, cols, x, v, w, part);
-  hipLaunchKernelGGL(s_bnorm, dim3(1), dim3(256), 0, stream, part, nb, sc);
-  hipLaunchKernelGGL(atu_kernel, dim3(nb), dim3(256), 0, stream, uh, uv, hole, v, rows, cols, sc, part);
-  hipLaunchKernelGGL(s_init_alfa, dim3(1), dim3(256), 0, stream, part, nb, sc);
-  hipLaunchKernelGGL(w_init_kernel, dim3(nb), dim3(256), 0, stream, v, w, n, sc);
-  SMRF_LAUNCH_CHECK();
-
+  const Band b = band_of(d_workspace, rows, cols, 0, 0);
+  if (int rc = init_scalars(b, atol, btol, conlim, iter_lim, stream)) return rc;
+  for (int ph : {PH_MASK, PH_RHS, PH_BNORM, PH_ATU, PH_INIT_ALFA})
+    if (int rc = run_phase(ph, d_A, b, stream)) return rc;
   Sc out{};
-  SMRF_HIP_CHECK(hipMemcpyAsync(&out, sc, sizeof(out), hipMemcpyDeviceToHost, stream));
+  SMRF_HIP_CHECK(hipMemcpyAsync(&out, b.sc, sizeof(out), hipMemcpyDeviceToHost, stream));
   SMRF_HIP_CHECK(hipStreamSynchronize(stream));
   const long long lim = out.iter_lim;
   int chunk = 4;
   while (!out.done && out.istop == 0 && out.itn < lim) {
-    for (int k = 0; k < chunk; ++k) {
-      hipLaunchKernelGGL(av_kernel, dim3(nb), dim3(256), 0, stream, uh, uv, hole, v, rows, cols, sc, part);
-      hipLaunchKernelGGL(s_beta, dim3(1), dim3(256), 0, stream, part, nb, sc);
-      hipLaunchKernelGGL(atu_kernel, dim3(nb), dim3(256), 0, stream, uh, uv, hole, v, rows, cols, sc, part);
-      hipLaunchKernelGGL(s_alfa_rot, dim3(1), dim3(256), 0, stream, part, nb, sc);
-      hipLaunchKernelGGL(xw_kernel, dim3(nb), dim3(256), 0, stream, x, w, v, hole, n, sc, part);
-      hipLaunchKernelGGL(s_tests, dim3(1), dim3(256), 0, stream, part, nb, sc);
-    }
-    SMRF_LAUNCH_CHECK();
-    SMRF_HIP_CHECK(hipMemcpyAsync(&out, sc, sizeof(out), hipMemcpyDeviceToHost, stream));
+    for (int k = 0; k < chunk; ++k)
+      for (int ph : {PH_AV, PH_BETA, PH_ATU, PH_ALFA_ROT, PH_XW, PH_TESTS})
+        if (int rc = run_phase(ph, d_A, b, stream)) return rc;
+    SMRF_HIP_CHECK(hipMemcpyAsync(&out, b.sc, sizeof(out), hipMemcpyDeviceToHost, stream));
     SMRF_HIP_CHECK(hipStreamSynchronize(stream));
     chunk = std::min(32, chunk * 2);
   }
   if (out.nunk > 0) {
-    hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, stream, d_A, x, hole, n);
-    SMRF_LAUNCH_CHECK();
+    if (int rc = run_phase(PH_SCATTER, d_A, b, stream)) return rc;
     SMRF_HIP_CHECK(hipStreamSynchronize(stream));
   }
   *h_istop = out.istop;
   *h_itn = (int64_t)out.itn;
+  if (h_n_unknown) *h_n_unknown = (int64_t)out.nunk;
+  return SMRF_OK;
+}
+
+size_t smrf_springs_band_workspace_bytes(int rows_local, int cols) { return layout_of(rows_local, cols).total; }
+
+int smrf_springs_band_layout(int rows_local, int cols, int64_t* h_out) {
+  if (!h_out || rows_local < 1 || cols < 1) return smrf_fail(SMRF_E_ARG, "bad band");
+  const Layout L = layout_of(rows_local, cols);
+  h_out[0] = (int64_t)L.v;       // v plane    (rows_local + 2 rows of cols doubles, row 0 = halo above)
+  h_out[1] = (int64_t)L.uv;      // uv plane   (same shape)
+  h_out[2] = (int64_t)L.hole;    // hole plane (rows_local + 2 rows of cols bytes)
+  h_out[3] = (int64_t)L.abelow;  // cols doubles: the raster row below the band
+  h_out[4] = (int64_t)L.red;     // 1 double: the phase sum to all-reduce
+  h_out[5] = (int64_t)L.total;
+  return SMRF_OK;
+}
+
+int smrf_springs_band_begin(int rows_local, int cols, double atol, double btol, double conlim, int64_t iter_lim,
+                            void* d_workspace, size_t workspace_bytes, void* stream) {
+  if (rows_local < 1 || cols < 1) return smrf_fail(SMRF_E_ARG, "bad band size %d x %d", rows_local, cols);
+  if (!d_workspace || workspace_bytes < layout_of(rows_local, cols).total)
+    return smrf_fail(SMRF_E_WORKSPACE, "springs band workspace too small");
+  const Band b = band_of(d_workspace, rows_local, cols, 0, 0);
+  SMRF_HIP_CHECK(hipMemsetAsync(d_workspace, 0, layout_of(rows_local, cols).total, (hipStream_t)stream));
+  return init_scalars(b, atol, btol, conlim, iter_lim, (hipStream_t)stream);
+}
+
+int smrf_springs_band_phase(int phase, double* d_A_band, int rows_local, int cols, int has_above, int has_below,
+                            void* d_workspace, size_t workspace_bytes, void* stream) {
+  if (!d_A_band || rows_local < 1 || cols < 1) return smrf_fail(SMRF_E_ARG, "bad band");
+  if (!d_workspace || workspace_bytes < layout_of(rows_local, cols).total)
+    return smrf_fail(SMRF_E_WORKSPACE, "springs band workspace too small");
+  const Band b = band_of(d_workspace, rows_local, cols, has_above != 0, has_below != 0);
+  return run_phase(phase, d_A_band, b, (hipStream_t)stream);
+}
+
+int smrf_springs_band_status(const void* d_workspace, int rows_local, int cols, int* h_istop, int64_t* h_itn,
+                             int64_t* h_n_unknown, int* h_done, void* stream) {
+  if (!d_workspace || !h_istop || !h_itn || !h_done) return smrf_fail(SMRF_E_ARG, "null pointer");
+  const Band b = band_of(const_cast<void*>(d_workspace), rows_local, cols, 0, 0);
+  Sc out{};
+  SMRF_HIP_CHECK(hipMemcpyAsync(&out, b.sc, sizeof(out), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  SMRF_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  *h_istop = out.istop;
+  *h_itn = (int64_t)out.itn;
+  *h_done = out.done || out.istop != 0 || out.itn >= out.iter_lim;
   if (h_n_unknown) *h_n_unknown = (int64_t)out.nunk;
   return SMRF_OK;
 }

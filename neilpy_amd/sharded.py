@@ -19,7 +19,8 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["band_rows", "HipBandOps", "progressive_filter_sharded"]
+__all__ = ["band_rows", "HipBandOps", "progressive_filter_sharded", "HipSpringsOps",
+           "inpaint_nans_by_springs_sharded", "create_dem_band"]
 
 
 def band_rows(img_rows, world_size, rank):
@@ -169,3 +170,174 @@ def progressive_filter_sharded(Z_band, img_rows, windows, thresholds, *, rank=No
         if len(windows) > 1:
             cur = 1 - cur
     return mask, when
+
+
+# ------------------------------------------------------------------------------------------
+# inpaint_nans_by_springs over row bands: 1-row halos + one scalar all-reduce per reduction
+# ------------------------------------------------------------------------------------------
+PH_MASK, PH_RHS, PH_BNORM, PH_ATU, PH_INIT_ALFA, PH_AV, PH_BETA, PH_ALFA_ROT, PH_XW, PH_TESTS, PH_SCATTER = range(11)
+
+
+class HipSpringsOps:
+    """The band phases of libsmrf_hip's LSQR (smrf_springs_band_*) on this rank's rows."""
+
+    def __init__(self, A_band, has_above, has_below):
+        import torch
+        self.lib = _lib.load()
+        _lib.require_gpu()
+        if A_band.dtype != torch.float64 or not A_band.is_contiguous() or not A_band.is_cuda:
+            raise TypeError("the band must be a contiguous float64 CUDA tensor")
+        self.A = A_band
+        self.rows, self.cols = A_band.shape
+        self.flags = (int(bool(has_above)), int(bool(has_below)))
+        self.nbytes = self.lib.smrf_springs_band_workspace_bytes(self.rows, self.cols)
+        self.ws = torch.empty(self.nbytes, dtype=torch.uint8, device=A_band.device)
+        lay = (C.c_int64 * 8)()
+        _lib.check(self.lib.smrf_springs_band_layout(self.rows, self.cols, lay))
+        n2 = (self.rows + 2) * self.cols
+        self.v = self.ws[lay[0]:lay[0] + n2 * 8].view(torch.float64).view(self.rows + 2, self.cols)
+        self.uv = self.ws[lay[1]:lay[1] + n2 * 8].view(torch.float64).view(self.rows + 2, self.cols)
+        self.hole = self.ws[lay[2]:lay[2] + n2].view(self.rows + 2, self.cols)
+        self.abelow = self.ws[lay[3]:lay[3] + self.cols * 8].view(torch.float64)
+        self.red = self.ws[lay[4]:lay[4] + 8].view(torch.float64)
+
+    def _stream(self):
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def begin(self, atol, btol, conlim, iter_lim):
+        _lib.check(self.lib.smrf_springs_band_begin(self.rows, self.cols, atol, btol, conlim, iter_lim,
+                                                    C.c_void_p(self.ws.data_ptr()), self.nbytes, self._stream()))
+
+    def phase(self, ph):
+        _lib.check(self.lib.smrf_springs_band_phase(ph, C.c_void_p(self.A.data_ptr()), self.rows, self.cols,
+                                                    self.flags[0], self.flags[1], C.c_void_p(self.ws.data_ptr()),
+                                                    self.nbytes, self._stream()))
+
+    def status(self):
+        istop, itn, nunk, done = C.c_int(0), C.c_int64(0), C.c_int64(0), C.c_int(0)
+        _lib.check(self.lib.smrf_springs_band_status(C.c_void_p(self.ws.data_ptr()), self.rows, self.cols, C.byref(istop),
+                                                     C.byref(itn), C.byref(nunk), C.byref(done), self._stream()))
+        return istop.value, itn.value, nunk.value, bool(done.value)
+
+
+def _shift(dist, group, rank, world, send, recv, up):
+    """up=True: every rank sends `send` to rank-1 and receives `recv` from rank+1 (down: the reverse)."""
+    dst, src = (rank - 1, rank + 1) if up else (rank + 1, rank - 1)
+
+    def peer(r):
+        return dist.get_global_rank(group, r) if group is not None else r
+    staged = dist.get_backend(group) == "gloo" and send.is_cuda
+    ops, back = [], None
+    if 0 <= dst < world:
+        ops.append(dist.P2POp(dist.isend, send.cpu() if staged else send.contiguous(), peer(dst), group))
+    if 0 <= src < world:
+        if staged:
+            back = recv.cpu()
+            ops.append(dist.P2POp(dist.irecv, back, peer(src), group))
+        else:
+            ops.append(dist.P2POp(dist.irecv, recv, peer(src), group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    if back is not None:
+        recv.copy_(back)
+
+
+def _allreduce_sum(dist, group, t):
+    if dist.get_backend(group) == "gloo" and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+def inpaint_nans_by_springs_sharded(A_band, img_rows, *, rank=None, world_size=None, group=None, ops=None,
+                                    atol=1e-6, btol=1e-6, conlim=1e8, iter_lim=-1, poll=8):
+    """Spring infill (SciPy-LSQR semantics) of a raster split into row bands; ``A_band`` (this rank's
+    rows, float64) is filled in place.  Returns ``(istop, itn, n_unknown)`` - equal on every rank.
+
+    Per LSQR iteration: rank r sends the first row of ``v`` up and the last row of ``uv`` down (one
+    row each, nearest neighbour) and three one-double all-reduces replace the three norms.  The
+    scalar recurrence runs replicated on every rank from the same reduced sums, so all ranks stop at
+    the same iteration.  Summation order differs from one device (block partials per band), so
+    values agree to ~1e-12 and ``itn`` is normally identical (hard part 1).
+    """
+    import torch.distributed as dist
+    if world_size is None:
+        world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    b0, b1 = band_rows(img_rows, world_size, rank)
+    if A_band.shape[0] != b1 - b0:
+        raise ValueError("band has %d rows, expected %d" % (A_band.shape[0], b1 - b0))
+    multi = world_size > 1
+    if ops is None:
+        ops = HipSpringsOps(A_band, rank > 0, rank < world_size - 1)
+    n = ops.rows
+
+    def reduce():
+        if multi:
+            _allreduce_sum(dist, group, ops.red)
+
+    ops.begin(atol, btol, conlim, iter_lim)
+    ops.phase(PH_MASK)
+    if multi:
+        _shift(dist, group, rank, world_size, ops.hole[1], ops.hole[n + 1], up=True)
+        _shift(dist, group, rank, world_size, ops.A[0], ops.abelow, up=True)
+    reduce()
+    ops.phase(PH_RHS)
+    reduce()
+    ops.phase(PH_BNORM)
+    if multi:
+        _shift(dist, group, rank, world_size, ops.uv[n], ops.uv[0], up=False)
+    ops.phase(PH_ATU)
+    reduce()
+    ops.phase(PH_INIT_ALFA)
+    istop, itn, nunk, done = ops.status()
+    while not done:
+        for _ in range(poll):
+            if multi:
+                _shift(dist, group, rank, world_size, ops.v[1], ops.v[n + 1], up=True)
+            ops.phase(PH_AV)
+            reduce()
+            ops.phase(PH_BETA)
+            if multi:
+                _shift(dist, group, rank, world_size, ops.uv[n], ops.uv[0], up=False)
+            ops.phase(PH_ATU)
+            reduce()
+            ops.phase(PH_ALFA_ROT)
+            ops.phase(PH_XW)
+            reduce()
+            ops.phase(PH_TESTS)
+        istop, itn, nunk, done = ops.status()
+    if nunk > 0:
+        ops.phase(PH_SCATTER)
+    return istop, itn, nunk
+
+
+def create_dem_band(xd, yd, zd, inv_affine, grid_shape, *, rank, world_size, bin_type='min'):
+    """This rank's row band of create_dem's raster from the FULL point set (points are replicated or
+    streamed to every rank; no exchange): returns (float64 band, uint8 empty mask, n_outside).
+
+    The binning kernel takes the band as (row0, rows_local) and ignores points of other bands, so N
+    ranks read the points N times but write disjoint rows (the all-to-all of points by
+    destination band is the alternative when the points do not fit every rank)."""
+    import torch
+    lib = _lib.load()
+    ny, nx = grid_shape
+    b0, b1 = band_rows(ny, world_size, rank)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    keys = torch.empty((b1 - b0, nx), dtype=torch.int64, device=xd.device)
+    n_out = torch.zeros(1, dtype=torch.int64, device=xd.device)
+    grid = torch.empty((b1 - b0, nx), dtype=torch.float64, device=xd.device)
+    empty = torch.empty((b1 - b0, nx), dtype=torch.uint8, device=xd.device)
+    h_inv = (C.c_double * 6)(*[float(v) for v in inv_affine])
+    is_max = 1 if bin_type == 'max' else 0
+    p = lambda t: C.c_void_p(t.data_ptr())
+    _lib.check(lib.smrf_grid_clear_u64(p(keys), keys.numel(), st))
+    _lib.check(lib.smrf_grid_bin_f64(p(xd), p(yd), p(zd), xd.numel(), h_inv, None, p(keys), ny, nx, b0, b1 - b0, is_max,
+                                     p(n_out), st))
+    _lib.check(lib.smrf_grid_finalize_f64(p(keys), p(grid), p(empty), keys.numel(), is_max, st))
+    return grid, empty, int(n_out.item())

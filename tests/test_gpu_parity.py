@@ -347,3 +347,25 @@ def test_smrf_pandas_series_in(nz):
     assert isinstance(out[3], pd.Series) and out[3].index.equals(df.index)
     assert np.array_equal(out[3].values, unpack(gold["is_object_point_bits"], (len(x),)))
     assert isinstance(out[0], np.ndarray) and isinstance(out[2], np.ndarray)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_sharded_stages_rehearsal(nz, world):
+    """create_dem band -> sharded LSQR -> sharded progressive_filter with the HIP band kernels on
+    1, 2 and 3 ranks sharing this GPU (gloo-staged halos) against samp11's goldens"""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = os.path.join(ROOT, "tools", "sharded_rehearsal.py")
+    if world == 1:
+        cmd = [sys.executable, script, "--sample", "samp11"]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(29620 + world), script, "--sample", "samp11",
+               "--backend", "gloo", "--share-gpu"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["create_dem_band_ok"] and j["lsqr_itn_ok"] and j["progressive_filter_ok"], j
+    assert j["inpaint_max_abs_err"] < 1e-7, j
