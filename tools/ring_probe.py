@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--radii", default="1,8,18,32,50")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--dilate", action="store_true")
+    ap.add_argument("--flag", action="store_true", help="time the dilation + flag step (smrf_pf_dilate_flag)")
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--libs", default="", help="comma list of extra libsmrf_hip builds to interleave (A/B in one process)")
     a = ap.parse_args()
@@ -31,10 +32,13 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(1)
     Z = torch.rand((n, n), dtype=dt, device="cuda", generator=g) * 50 + 300
     out = torch.empty_like(Z)
-    fns = {"cur": getattr(lib, "smrf_disk_filter_" + a.dtype)}
+    fname = ("smrf_pf_dilate_flag_" if a.flag else "smrf_disk_filter_") + a.dtype
+    fns = {"cur": getattr(lib, fname)}
+    last = (Z + 0.4) if a.flag else None
+    mask = torch.zeros((n, n), dtype=torch.uint8, device="cuda") if a.flag else None
     for path in [v for v in a.libs.split(",") if v]:
         other = C.CDLL(os.path.abspath(path))
-        f = getattr(other, "smrf_disk_filter_" + a.dtype)
+        f = getattr(other, fname)
         f.restype, f.argtypes = fns["cur"].restype, fns["cur"].argtypes
         fns[os.path.basename(path)] = f
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -61,8 +65,12 @@ def main():
             for name, fn in fns.items():           # interleaved rounds: same box, same clocks
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                rc = fn(C.c_void_p(Z.data_ptr()), C.c_void_p(out.data_ptr()), n, n, n, 0, n, 0, n, r,
-                        int(a.dilate), 0, 0, st)
+                if a.flag:
+                    rc = fn(C.c_void_p(Z.data_ptr()), C.c_void_p(last.data_ptr()), C.c_void_p(out.data_ptr()),
+                            C.c_void_p(mask.data_ptr()), None, 0.15 * r, 3, n, n, n, 0, n, 0, n, r, 0, 0, st)
+                else:
+                    rc = fn(C.c_void_p(Z.data_ptr()), C.c_void_p(out.data_ptr()), n, n, n, 0, n, 0, n, r,
+                            int(a.dilate), 0, 0, st)
                 assert rc == 0, rc
                 e1.record()
                 torch.cuda.synchronize()
