@@ -17,6 +17,8 @@
  *   smrf_springs_lsqr_f64     inpaint_nans_by_springs(), neilpy/neilpy.py:1227-1271, whose
  *                             solve is scipy.sparse.linalg.lsqr (:1264)
  *   smrf_gradient_slope_f64   np.gradient + sqrt, neilpy/neilpy.py:1785-1786
+ *   smrf_las_decode_xyz_f64   the coordinate decode of read_las(), neilpy/neilpy.py:903-1087 (host
+ *                             side: neilpy_amd/las.py)
  *   smrf_spline_solve_f64, smrf_spline_eval_f64, smrf_classify_points_f64
  *                             RectBivariateSpline(...).ev and the point test, neilpy/neilpy.py:1768-1795
  *   smrf_negate_f64, smrf_mask_apply_f64
@@ -132,6 +134,11 @@ SMRF_API int smrf_count_nan_f64(const double* d_a, int64_t n, int64_t* h_count, 
  * workspace: 4 * 1024 doubles. */
 SMRF_API int smrf_points_extent_f64(const double* d_x, const double* d_y, int64_t n, double* h_out,
                            void* d_workspace, size_t workspace_bytes, void* stream);
+/* LAS point records (packed, record_length bytes each, x/y/z int32 first) -> float64 coordinates
+ * x = X * scale + offset (neilpy.py:1055-1057 in read_las); h_scale_offset = {sx, sy, sz, ox, oy, oz} */
+SMRF_API int smrf_las_decode_xyz_f64(const uint8_t* d_records, int64_t npts, int record_length,
+                            const double* h_scale_offset, double* d_x, double* d_y, double* d_z,
+                            void* stream);
 /* fractional pixel coordinates (col, row) = ~t * (x, y) with h_inv = (a,b,c,d,e,f) of the inverse
  * transform, products and sums rounded separately like the affine package (neilpy.py:1772) */
 SMRF_API int smrf_affine_apply_f64(const double* d_x, const double* d_y, int64_t npts, const double* h_inv,

@@ -9,6 +9,7 @@ from ._lib import SmrfHipError, load as load_library, LIB_PATH          # noqa: 
 from .affine import Affine, from_origin                                  # noqa: F401
 from .api import (create_dem, dilation, disk, erosion, inpaint_nans_by_springs, last_stats,   # noqa: F401
                   opening, progressive_filter, smrf)
+from .las import read_las, read_las_xyz, write_las                         # noqa: F401
 from .synth import synth_dem, synth_points                               # noqa: F401
 
 __version__ = "0.1.0"

@@ -38,6 +38,7 @@ SIGNATURES = {
     "smrf_count_nan_f32": (_i, [_p, _i64, C.POINTER(_i64), _p]),
     "smrf_count_nan_f64": (_i, [_p, _i64, C.POINTER(_i64), _p]),
     "smrf_points_extent_f64": (_i, [_p, _p, _i64, C.POINTER(_d), _p, _sz, _p]),
+    "smrf_las_decode_xyz_f64": (_i, [_p, _i64, _i, C.POINTER(_d), _p, _p, _p, _p]),
     "smrf_affine_apply_f64": (_i, [_p, _p, _i64, C.POINTER(_d), _p, _p, _p]),
     "smrf_grid_clear_u64": (_i, [_p, _i64, _p]),
     "smrf_grid_bin_f64": (_i, [_p, _p, _p, _i64, C.POINTER(_d), C.POINTER(_d), _p, _i, _i, _i, _i, _i, _p, _p]),

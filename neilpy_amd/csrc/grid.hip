@@ -110,6 +110,26 @@ __global__ __launch_bounds__(256) void affine_kernel(const double* __restrict__ 
   }
 }
 
+// LAS point records -> float64 coordinates: x = int32 * scale + offset, product and sum rounded
+// separately (the reference's pandas arithmetic, neilpy.py:1055-1057).  Records are packed and
+// unaligned (20..67+ bytes), so the three int32 are assembled from bytes.
+__global__ __launch_bounds__(256) void las_decode_kernel(const uint8_t* __restrict__ rec, long long n, int reclen,
+                                                         double sx, double sy, double sz, double ox, double oy, double oz,
+                                                         double* __restrict__ x, double* __restrict__ y,
+                                                         double* __restrict__ z) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const uint8_t* p = rec + i * reclen;
+    int v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      v[k] = (int)((unsigned)p[4 * k] | ((unsigned)p[4 * k + 1] << 8) | ((unsigned)p[4 * k + 2] << 16) |
+                   ((unsigned)p[4 * k + 3] << 24));
+    x[i] = __dadd_rn(__dmul_rn((double)v[0], sx), ox);
+    y[i] = __dadd_rn(__dmul_rn((double)v[1], sy), oy);
+    z[i] = __dadd_rn(__dmul_rn((double)v[2], sz), oz);
+  }
+}
+
 int nblocks(long long n, int cap) { return (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, cap)); }
 
 }  // namespace
@@ -146,6 +166,18 @@ int smrf_affine_apply_f64(const double* d_x, const double* d_y, int64_t npts, co
   if (npts == 0) return SMRF_OK;
   hipLaunchKernelGGL(affine_kernel, dim3(nblocks(npts, 8192)), dim3(256), 0, (hipStream_t)stream, d_x, d_y,
                      (long long)npts, h_inv[0], h_inv[1], h_inv[2], h_inv[3], h_inv[4], h_inv[5], d_col, d_row);
+  SMRF_LAUNCH_CHECK();
+  return SMRF_OK;
+}
+
+int smrf_las_decode_xyz_f64(const uint8_t* d_records, int64_t npts, int record_length, const double* h_scale_offset,
+                            double* d_x, double* d_y, double* d_z, void* stream) {
+  if (npts < 0 || record_length < 12 || !h_scale_offset || (npts > 0 && (!d_records || !d_x || !d_y || !d_z)))
+    return smrf_fail(SMRF_E_ARG, "bad LAS decode arguments");
+  if (npts == 0) return SMRF_OK;
+  hipLaunchKernelGGL(las_decode_kernel, dim3(nblocks(npts, 8192)), dim3(256), 0, (hipStream_t)stream, d_records,
+                     (long long)npts, record_length, h_scale_offset[0], h_scale_offset[1], h_scale_offset[2],
+                     h_scale_offset[3], h_scale_offset[4], h_scale_offset[5], d_x, d_y, d_z);
   SMRF_LAUNCH_CHECK();
   return SMRF_OK;
 }

@@ -436,14 +436,58 @@ def golden_create_dem(ref, rec, out):
     np.savez_compressed(os.path.join(out, "create_dem.npz"), **d)
 
 
+def golden_las(ref, out):
+    """LAS files written by neilpy_amd.las.write_las (formats 0-10, LAS 1.2/1.3/1.4), read back by the
+    REFERENCE's read_las: header dictionary and every DataFrame column are the golden."""
+    from neilpy_amd.las import write_las, record_dtype
+    d = os.path.join(out, "las")
+    os.makedirs(d, exist_ok=True)
+    rng = np.random.default_rng(2024)
+    res = {}
+    cases = []
+    for fmt in range(11):
+        n = 150 + 7 * fmt
+        x = np.round(rng.uniform(864597.5, 864700.0, n), 2)
+        y = np.round(rng.uniform(1919707.5, 1919800.0, n), 2)
+        z = np.round(rng.uniform(100.0, 140.0, n), 2)
+        dt = record_dtype(fmt)
+        fields = {}
+        for name in dt.names:
+            if name in ("x", "y", "z"):
+                continue
+            k = dt[name].kind
+            if k == "u":
+                fields[name] = rng.integers(0, 2 ** (8 * dt[name].itemsize), n, dtype=np.uint64).astype(dt[name])
+            elif k == "f":
+                fields[name] = rng.normal(0, 100, n).astype(dt[name])
+        version = (1, 4) if fmt >= 6 else ((1, 3) if fmt in (4, 5) else (1, 2))
+        fn = os.path.join(d, "pdrf%d.las" % fmt)
+        write_las(fn, x, y, z, fmt=fmt, version=version, fields=fields)
+        header, df = ref.read_las(fn)
+        tag = "pdrf%d" % fmt
+        cases.append(tag)
+        res[tag + "_header_json"] = np.array(json.dumps({k: (list(v) if isinstance(v, tuple) else v)
+                                                         for k, v in header.items()}))
+        res[tag + "_columns"] = np.array(list(df.columns))
+        for c in df.columns:
+            res[tag + "_col_" + c] = df[c].values
+        print("las", tag, df.shape, header["version"], flush=True)
+    res["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(out, "las.npz"), **res)
+
+
 def main():
     out = HERE
     ref = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "las":
+        golden_las(ref, out)
+        return
     rec = Recorder(ref)
     golden_samples(out)
     golden_progressive_filter(ref, rec, out)
     golden_inpaint(ref, rec, out)
     golden_create_dem(ref, rec, out)
+    golden_las(ref, out)
     anchors, published = golden_smrf(ref, rec, out)
     meta = dict(
         generated_by="tests/golden/make_golden.py (reference imported from /root/reference)",

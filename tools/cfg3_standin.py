@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""cfg3 stand-in: full smrf() from a LAS file at 0.5 cellsize.
+
+sample_data/DK22_partial.las is absent from the reference checkout (.MISSING_LARGE_BLOBS), so the
+input is a synthetic LAS 1.2 / PDRF 1 file with DK22's extent (3580 x 2485 ft, origin
+(864597.5, 1919707.5), from examples/dk22_smrfed.tif's tags per SURVEY 7.7) written by
+neilpy_amd.las.write_las from a seeded generator.  Prints one JSON line with per-step timings."""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ap = argparse.ArgumentParser()
+ap.add_argument("--points", type=int, default=12_000_000)
+ap.add_argument("--cellsize", type=float, default=0.5)
+ap.add_argument("--windows", type=int, default=18)
+a = ap.parse_args()
+import torch  # noqa: E402
+import neilpy_amd  # noqa: E402
+
+rng = np.random.default_rng(2022)
+W, H = 3580.0, 2485.0
+x = np.round(864597.5 + rng.uniform(0, W, a.points), 2)
+y = np.round(1919707.5 + rng.uniform(0, H, a.points), 2)
+z = neilpy_amd.synth.terrain(x - 864597.5, y - 1919707.5) * 0.3 + 100.0
+z = np.round(z + np.abs(rng.normal(0, 0.5, a.points)) * (rng.random(a.points) < 0.25) * 25.0, 2)
+fn = os.path.join(tempfile.mkdtemp(), "dk22_standin.las")
+neilpy_amd.write_las(fn, x, y, z, fmt=1, scale=(0.01, 0.01, 0.01), offset=(864000.0, 1919000.0, 0.0))
+out = {"file_MB": round(os.path.getsize(fn) / 1e6, 1), "points": a.points, "cellsize": a.cellsize, "windows": a.windows}
+t0 = time.perf_counter()
+header, xd, yd, zd = neilpy_amd.read_las_xyz(fn)
+torch.cuda.synchronize()
+out["read_las_xyz_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+for rep in range(2):
+    t0 = time.perf_counter()
+    dtm, T, obj, pts = neilpy_amd.smrf(xd, yd, zd, cellsize=a.cellsize, windows=a.windows)
+    torch.cuda.synchronize()
+    out["smrf_ms_run%d" % rep] = round((time.perf_counter() - t0) * 1e3, 1)
+out.update(grid=list(dtm.shape), object_cells=int(obj.sum()), object_points=int(np.asarray(pts).sum()),
+           lsqr=[neilpy_amd.last_stats["inpaint1"], neilpy_amd.last_stats["inpaint2"]],
+           Mpoints_per_s=round(a.points / out["smrf_ms_run1"] / 1e3, 2))
+print(json.dumps(out))
