@@ -51,6 +51,12 @@ struct Band {
   int rows, cols, has_above, has_below;
 };
 
+// 2-D walk over the band's cells without an integer division per cell: blockIdx.x picks 256 columns,
+// blockIdx.y strides over the rows.  Defines r, c and the flat index i.
+#define SMRF_FOR_CELLS(rows_, cols_)                                                        \
+  for (int r = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x; r < (rows_); r += gridDim.y) \
+    for (long long i = (long long)r * (cols_) + c; c < (cols_) && i >= 0; i = -1)
+
 __device__ __forceinline__ double block_sum(double s, double* red) {
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
   const int w = threadIdx.x >> 6;
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(256) void mask_kernel(const double* __restrict__ A,
     c += h ? 1.0 : 0.0;
   }
   const double t = block_sum(c, red);
-  if (threadIdx.x == 0) b.part[blockIdx.x] = t;
+  if (threadIdx.x == 0) b.part[blockIdx.y * gridDim.x + blockIdx.x] = t;
 }
 
 // rhs = -S_known @ A_known  (neilpy.py:1263): on an active edge, K[hi] - K[lo] with K = 0 at holes
@@ -93,8 +99,7 @@ __global__ __launch_bounds__(256) void rhs_kernel(const double* __restrict__ A, 
   const int rows = b.rows, cols = b.cols;
   const long long n = (long long)rows * cols;
   double s = 0.0;
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
+  SMRF_FOR_CELLS(rows, cols) {
     const bool h0 = b.hole[i];
     const double k0 = h0 ? 0.0 : A[i];
     double eh = 0.0, ev = 0.0;
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(256) void rhs_kernel(const double* __restrict__ A, 
     s += ev * ev;
   }
   const double t = block_sum(s, red);
-  if (threadIdx.x == 0) b.part[blockIdx.x] = t;
+  if (threadIdx.x == 0) b.part[blockIdx.y * gridDim.x + blockIdx.x] = t;
 }
 
 __global__ void s_count(const Band b) {
@@ -146,9 +151,8 @@ __global__ __launch_bounds__(256) void atu_kernel(const Band b) {
   const int rows = b.rows, cols = b.cols;
   const long long n = (long long)rows * cols;
   double s = 0.0;
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+  SMRF_FOR_CELLS(rows, cols) {
     if (!b.hole[i]) continue;
-    const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
     double y = 0.0;
     if (r > 0 || b.has_above) y = y - ib * b.uv[i - cols];
     if (c > 0) y = y - ib * b.uh[i - 1];
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256) void atu_kernel(const Band b) {
     s += nv * nv;
   }
   const double t = block_sum(s, red);
-  if (threadIdx.x == 0) b.part[blockIdx.x] = t;
+  if (threadIdx.x == 0) b.part[blockIdx.y * gridDim.x + blockIdx.x] = t;
 }
 
 __global__ void s_init_alfa(const Band b) {
@@ -189,8 +193,7 @@ __global__ __launch_bounds__(256) void av_kernel(const Band b) {
   const int rows = b.rows, cols = b.cols;
   const long long n = (long long)rows * cols;
   double s = 0.0;
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
+  SMRF_FOR_CELLS(rows, cols) {
     const bool h0 = b.hole[i];
     const double v0 = ia * b.v[i];
     if (c + 1 < cols) {
@@ -209,13 +212,11 @@ __global__ __launch_bounds__(256) void av_kernel(const Band b) {
     }
   }
   const double t = block_sum(s, red);
-  if (threadIdx.x == 0) b.part[blockIdx.x] = t;
+  if (threadIdx.x == 0) b.part[blockIdx.y * gridDim.x + blockIdx.x] = t;
 }
 
-__global__ void s_beta(const Band b) {
-  Sc* sc = b.sc;
-  if (stopped(sc)) return;
-  const double bt = sqrt(b.red[0]);
+__device__ void beta_step(Sc* sc, double sum_u) {
+  const double bt = sqrt(sum_u);
   sc->beta = bt;
   sc->beta_pos = bt > 0;
   if (bt > 0) {
@@ -225,14 +226,16 @@ __global__ void s_beta(const Band b) {
     sc->inv_beta = 1.0;   // scipy leaves u unscaled when beta == 0
   }
 }
+__global__ void s_beta(const Band b) {
+  if (stopped(b.sc)) return;
+  beta_step(b.sc, b.red[0]);
+}
 
 __device__ __forceinline__ double sgn(double a) { return a > 0 ? 1.0 : (a < 0 ? -1.0 : 0.0); }
 
-__global__ void s_alfa_rot(const Band bd) {
-  Sc* sc = bd.sc;
-  if (stopped(sc)) return;
+__device__ void alfa_rot_step(Sc* sc, double sum_v) {
   if (sc->beta_pos) {
-    const double a = sqrt(bd.red[0]);
+    const double a = sqrt(sum_v);
     sc->alfa = a;
     sc->inv_alfa = a > 0 ? 1 / a : 1.0;
   }
@@ -263,8 +266,12 @@ __global__ void s_alfa_rot(const Band bd) {
   sc->sn2 = theta / gamma;
   sc->z = rhs / gamma;
   sc->xxnorm = sc->xxnorm + sc->z * sc->z;
-  sc->xnorm = xnorm;   // for s_tests
+  sc->xnorm = xnorm;   // for the stopping tests
   sc->tau = tau;
+}
+__global__ void s_alfa_rot(const Band b) {
+  if (stopped(b.sc)) return;
+  alfa_rot_step(b.sc, b.red[0]);
 }
 
 // ---- x += t1*w ; w = v_s + t2*w ; partial |w/rho|^2 ------------------------------------------
@@ -284,15 +291,13 @@ __global__ __launch_bounds__(256) void xw_kernel(const Band b) {
     s += dk * dk;
   }
   const double t = block_sum(s, red);
-  if (threadIdx.x == 0) b.part[blockIdx.x] = t;
+  if (threadIdx.x == 0) b.part[blockIdx.y * gridDim.x + blockIdx.x] = t;
 }
 
-__global__ void s_tests(const Band b) {
-  Sc* sc = b.sc;
-  if (stopped(sc)) return;
+__device__ void tests_step(Sc* sc, double sum_dk) {
   const double EPS = 2.220446049250313e-16;
   const double xnorm = sc->xnorm, tau = sc->tau;
-  const double nd = sqrt(b.red[0]);
+  const double nd = sqrt(sum_dk);
   sc->ddnorm = sc->ddnorm + nd * nd;
   sc->itn += 1;
   const double anorm = sc->anorm, bnorm = sc->bnorm;
@@ -314,6 +319,77 @@ __global__ void s_tests(const Band b) {
   if (test1 <= rtol) istop = 1;
   sc->istop = istop;
 }
+__global__ void s_tests(const Band b) {
+  if (stopped(b.sc)) return;
+  tests_step(b.sc, b.red[0]);
+}
+
+// ---- single-device fast path: xw of iteration i fused with av of iteration i+1 ---------------
+// (both walk the same cells; the u update of a stopping iteration is wasted but harmless).
+// red[0] <- |w/rho|^2 (iteration i), red[1] <- |u|^2 (iteration i+1), via part[] and part[MAXB..].
+__global__ __launch_bounds__(256) void xwav_kernel(const Band b) {
+  __shared__ double red[4];
+  __shared__ double red2[4];
+  const Sc* sc = b.sc;
+  if (stopped(sc)) return;
+  const double t1 = sc->t1, t2 = sc->t2, ir = sc->inv_rho, ia = sc->inv_alfa, ib = sc->inv_beta, alfa = sc->alfa;
+  const int rows = b.rows, cols = b.cols;
+  const long long n = (long long)rows * cols;
+  double sd = 0.0, su = 0.0;
+  SMRF_FOR_CELLS(rows, cols) {
+    const bool h0 = b.hole[i];
+    const double v0 = ia * b.v[i];
+    if (h0) {
+      const double ws = b.w[i];
+      const double dk = ir * ws;
+      b.x[i] = b.x[i] + t1 * ws;
+      b.w[i] = v0 + t2 * ws;
+      sd += dk * dk;
+    }
+    if (c + 1 < cols) {
+      if (h0 | b.hole[i + 1]) {
+        const double nu = (v0 - ia * b.v[i + 1]) - alfa * (ib * b.uh[i]);
+        b.uh[i] = nu;
+        su += nu * nu;
+      }
+    }
+    if (r + 1 < rows) {
+      if (h0 | b.hole[i + cols]) {
+        const double nu = (v0 - ia * b.v[i + cols]) - alfa * (ib * b.uv[i]);
+        b.uv[i] = nu;
+        su += nu * nu;
+      }
+    }
+  }
+  const double td = block_sum(sd, red);
+  const double tu = block_sum(su, red2);
+  if (threadIdx.x == 0) { b.part[blockIdx.y * gridDim.x + blockIdx.x] = td; b.part[MAXB + blockIdx.y * gridDim.x + blockIdx.x] = tu; }
+}
+
+// reduce the block partials and run the scalar step(s) in the same launch (one block)
+template <int WHAT>   // 0: beta   1: alfa + rotation   2: tests(i) then beta(i+1)
+__global__ __launch_bounds__(256) void reduce_scalar_kernel(const Band b, int nb) {
+  __shared__ double red[4];
+  __shared__ double red2[4];
+  Sc* sc = b.sc;
+  if (stopped(sc)) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256) {
+    s0 += b.part[i];
+    if (WHAT == 2) s1 += b.part[MAXB + i];
+  }
+  const double t0 = block_sum(s0, red);
+  const double t1 = WHAT == 2 ? block_sum(s1, red2) : 0.0;
+  if (threadIdx.x == 0) {
+    if (WHAT == 0) beta_step(sc, t0);
+    if (WHAT == 1) alfa_rot_step(sc, t0);
+    if (WHAT == 2) {
+      tests_step(sc, t0);
+      if (sc->istop == 0) beta_step(sc, t1);
+    }
+  }
+}
+
 
 __global__ __launch_bounds__(256) void scatter_kernel(double* __restrict__ A, const Band b) {
   const long long n = (long long)b.rows * b.cols;
@@ -340,7 +416,7 @@ Layout layout_of(int rows, int cols) {
   L.uv = o; o += L.plane;
   L.hole = o; o += align_up(n2);
   L.abelow = o; o += align_up((size_t)cols * sizeof(double));
-  L.part = o; o += align_up(MAXB * sizeof(double));
+  L.part = o; o += align_up(2 * MAXB * sizeof(double));
   L.red = o; o += 256;
   L.sc = o; o += align_up(sizeof(Sc));
   L.total = o;
@@ -382,26 +458,35 @@ enum Phase {
   PH_SCATTER = 10,  // A[hole] = x
 };
 
+// 2-D launch of the stencil kernels: 256 columns per block, rows strided over gridDim.y; at most MAXB blocks
+dim3 grid2d(const Band& b) {
+  const int cb = (b.cols + 255) / 256;
+  const int rb = std::max(1, std::min(b.rows, MAXB / std::max(cb, 1)));
+  return dim3(cb, std::max(rb, 1));
+}
+
 int run_phase(int phase, double* A, const Band& b, hipStream_t st) {
   const int nb = nblocks(b);
-  auto reduce = [&]() { hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(256), 0, st, (const double*)b.part, nb, b.red); };
+  const dim3 g2 = grid2d(b);
+  const int nb2 = (int)(g2.x * g2.y);
+  auto reduce = [&](int count) { hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(256), 0, st, (const double*)b.part, count, b.red); };
   switch (phase) {
-    case PH_MASK: hipLaunchKernelGGL(mask_kernel, dim3(nb), dim3(256), 0, st, (const double*)A, b); reduce(); break;
+    case PH_MASK: hipLaunchKernelGGL(mask_kernel, dim3(nb), dim3(256), 0, st, (const double*)A, b); reduce(nb); break;
     case PH_RHS:
       hipLaunchKernelGGL(s_count, dim3(1), dim3(1), 0, st, b);
-      hipLaunchKernelGGL(rhs_kernel, dim3(nb), dim3(256), 0, st, (const double*)A, b);
-      reduce();
+      hipLaunchKernelGGL(rhs_kernel, g2, dim3(256), 0, st, (const double*)A, b);
+      reduce(nb2);
       break;
     case PH_BNORM: hipLaunchKernelGGL(s_bnorm, dim3(1), dim3(1), 0, st, b); break;
-    case PH_ATU: hipLaunchKernelGGL(atu_kernel, dim3(nb), dim3(256), 0, st, b); reduce(); break;
+    case PH_ATU: hipLaunchKernelGGL(atu_kernel, g2, dim3(256), 0, st, b); reduce(nb2); break;
     case PH_INIT_ALFA:
       hipLaunchKernelGGL(s_init_alfa, dim3(1), dim3(1), 0, st, b);
       hipLaunchKernelGGL(w_init_kernel, dim3(nb), dim3(256), 0, st, b);
       break;
-    case PH_AV: hipLaunchKernelGGL(av_kernel, dim3(nb), dim3(256), 0, st, b); reduce(); break;
+    case PH_AV: hipLaunchKernelGGL(av_kernel, g2, dim3(256), 0, st, b); reduce(nb2); break;
     case PH_BETA: hipLaunchKernelGGL(s_beta, dim3(1), dim3(1), 0, st, b); break;
     case PH_ALFA_ROT: hipLaunchKernelGGL(s_alfa_rot, dim3(1), dim3(1), 0, st, b); break;
-    case PH_XW: hipLaunchKernelGGL(xw_kernel, dim3(nb), dim3(256), 0, st, b); reduce(); break;
+    case PH_XW: hipLaunchKernelGGL(xw_kernel, dim3(nb), dim3(256), 0, st, b); reduce(nb); break;
     case PH_TESTS: hipLaunchKernelGGL(s_tests, dim3(1), dim3(1), 0, st, b); break;
     case PH_SCATTER: hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, st, A, b); break;
     default: return smrf_fail(SMRF_E_ARG, "unknown springs phase %d", phase);
@@ -441,11 +526,24 @@ int smrf_springs_lsqr_f64(double* d_A, int rows, int cols, double atol, double b
   SMRF_HIP_CHECK(hipMemcpyAsync(&out, b.sc, sizeof(out), hipMemcpyDeviceToHost, stream));
   SMRF_HIP_CHECK(hipStreamSynchronize(stream));
   const long long lim = out.iter_lim;
+  const dim3 g2 = grid2d(b);
+  const int nb = (int)(g2.x * g2.y);
+  // Iteration i = [u = S v - alfa u; beta] [v = S^T u - beta v; alfa, rotation] [x, w update; tests].
+  // Four launches per iteration: atu | reduce+alfa_rot | xw(i) fused with av(i+1) | reduce+tests(i)+beta(i+1).
+  if (!out.done && out.istop == 0 && out.itn < lim) {
+    hipLaunchKernelGGL(av_kernel, g2, dim3(256), 0, stream, b);
+    hipLaunchKernelGGL(reduce_scalar_kernel<0>, dim3(1), dim3(256), 0, stream, b, nb);
+    SMRF_LAUNCH_CHECK();
+  }
   int chunk = 4;
   while (!out.done && out.istop == 0 && out.itn < lim) {
-    for (int k = 0; k < chunk; ++k)
-      for (int ph : {PH_AV, PH_BETA, PH_ATU, PH_ALFA_ROT, PH_XW, PH_TESTS})
-        if (int rc = run_phase(ph, d_A, b, stream)) return rc;
+    for (int k = 0; k < chunk; ++k) {
+      hipLaunchKernelGGL(atu_kernel, g2, dim3(256), 0, stream, b);
+      hipLaunchKernelGGL(reduce_scalar_kernel<1>, dim3(1), dim3(256), 0, stream, b, nb);
+      hipLaunchKernelGGL(xwav_kernel, g2, dim3(256), 0, stream, b);
+      hipLaunchKernelGGL(reduce_scalar_kernel<2>, dim3(1), dim3(256), 0, stream, b, nb);
+    }
+    SMRF_LAUNCH_CHECK();
     SMRF_HIP_CHECK(hipMemcpyAsync(&out, b.sc, sizeof(out), hipMemcpyDeviceToHost, stream));
     SMRF_HIP_CHECK(hipStreamSynchronize(stream));
     chunk = std::min(32, chunk * 2);
