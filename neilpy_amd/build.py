@@ -44,7 +44,7 @@ def units():
 def newest_header():
     t = os.path.getmtime(os.path.join(ROOT, "include", "smrf_hip.h"))
     for f in os.listdir(CSRC):
-        if f.endswith(".h"):
+        if f.endswith((".h", ".inc")):
             t = max(t, os.path.getmtime(os.path.join(CSRC, f)))
     return t
 

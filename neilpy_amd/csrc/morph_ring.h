@@ -37,6 +37,14 @@
 #ifndef SMRF_RING_G
 #define SMRF_RING_G(ringregs) (((ringregs) > 116 && (ringregs) <= 132) ? 2 : 4)
 #endif
+// tuning builds (-DSMRF_RING_NO_TUNE): most row pairs per batch the chooser ring_np() may pick
+// (fp32; fp64 cells are twice as large: half) for every radius; product builds read ring_tune.inc
+#ifndef SMRF_RING_NP_MAX
+#define SMRF_RING_NP_MAX 2
+#endif
+#ifndef SMRF_RING_OCC_DROP
+#define SMRF_RING_OCC_DROP 0   // tuning builds: run every radius one occupancy step below the estimate
+#endif
 #ifndef SMRF_FORCE_OCC
 #define SMRF_OCC_OVERRIDE(...) __VA_ARGS__
 #else
@@ -44,6 +52,14 @@
 #endif
 
 namespace smrf {
+
+// one step down the occupancy ladder the kernels are built for (waves per SIMD)
+constexpr int ring_occ_drop(int occ, int steps) {
+  for (; steps > 0; --steps) occ = occ > 5 ? 5 : occ > 1 ? occ - 1 : 1;
+  return occ;
+}
+
+#include "ring_tune.inc"
 
 constexpr int clog2(int v) {  // floor(log2(v)), v >= 1
   int l = 0;
@@ -193,7 +209,8 @@ struct RingCfg {
     return n;
   }
   static constexpr int NEED = NEED_BASE + (D - 2) * 4 * G * E;
-  static constexpr int OCC_REG = NEED <= 64 ? 8 : NEED <= 96 ? 5 : NEED <= 128 ? 4 : NEED <= 168 ? 3 : NEED <= 264 ? 2 : 1;
+  static constexpr int OCC_EST = NEED <= 64 ? 8 : NEED <= 96 ? 5 : NEED <= 128 ? 4 : NEED <= 168 ? 3 : NEED <= 264 ? 2 : 1;
+  static constexpr int OCC_REG = ring_occ_drop(OCC_EST, ring_tuned_occ_drop<T>(R));
   static constexpr int WAVES = TW / 64;                  // waves per workgroup
   static constexpr int WG_LDS = (int)(160 * 1024 / LDS_BYTES) < 1 ? 1 : (int)(160 * 1024 / LDS_BYTES);
   static constexpr int OCC_LDS = WG_LDS * WAVES / 4 < 1 ? 1 : WG_LDS * WAVES / 4;
@@ -210,6 +227,21 @@ struct RingCfg {
     return k == 0 ? 0 : (k - 1) / G;
   }
 };
+
+// Row pairs per batch: the most (up to SMRF_RING_NP_MAX) whose tables still leave room in the
+// CU's 160 KB of LDS for every workgroup the register budget allows.  More pairs per batch spread
+// the three barriers and the table build's latency over more output rows.
+template <typename T, int R, int TW>
+constexpr int ring_np() {
+  constexpr int mx = sizeof(T) == 4 ? ring_tuned_np_max<T>(R) : (ring_tuned_np_max<T>(R) / 2 < 1 ? 1 : ring_tuned_np_max<T>(R) / 2);
+  using C1 = RingCfg<T, R, TW, 1>;
+  constexpr int want = C1::OCC_REG * 4 / C1::WAVES < 1 ? 1 : C1::OCC_REG * 4 / C1::WAVES;   // workgroups per CU
+  if constexpr (mx >= 4) if (RingCfg<T, R, TW, 4>::WG_LDS >= want) return 4;
+  if constexpr (mx >= 3) if (RingCfg<T, R, TW, 3>::WG_LDS >= want) return 3;
+  if constexpr (mx >= 2) if (RingCfg<T, R, TW, 2>::WG_LDS >= want) return 2;
+  return 1;
+}
+#define SMRF_RING_NP(T, R) ring_np<T, R, SMRF_RING_TW>()
 
 // Diagnostic build only (-DSMRF_STAMPS): per-phase wave-cycle sums, written to a buffer of their own
 // (never read by the kernel, never part of an output).  Not compiled into the product library.
@@ -578,7 +610,7 @@ void ring_kernel(const DiskArgs<T> a) {
 template <typename T, int R, bool DIL>
 int ring_launch(const DiskArgs<T>& a_in, hipStream_t stream) {
   constexpr int TW = SMRF_RING_TW;
-  constexpr int NP = sizeof(T) == 4 ? 2 : 1;
+  constexpr int NP = SMRF_RING_NP(T, R);
   using C = RingCfg<T, R, TW, NP>;
   auto kern = ring_kernel<T, R, DIL, TW, NP>;
   static bool attr_done = false;

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Per-radius tuning of the ring kernels on the GPU at hand (developer tool).
+
+Builds to compare are variant libraries made by ``python -m neilpy_amd.build --variant nMdD
+"--defs=-DSMRF_RING_NO_TUNE -DSMRF_RING_NP_MAX=M -DSMRF_RING_OCC_DROP=D"``.  For every radius the
+tool times one progressive-filter window (erosion, then dilation + flagging: the two launches the
+headline benchmark is made of) on the benchmark DEM with every build interleaved in one process,
+and prints the table that goes into neilpy_amd/csrc/ring_tune.inc.
+
+    python tools/ring_tune.py --dtype f32 --variants n2d0,n3d0,n4d0,n2d1,n3d1,n4d1 [--emit gpurun_out/ring_tune_f32.json]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import re
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=16384)
+    ap.add_argument("--rmax", type=int, default=64)
+    ap.add_argument("--reps", type=int, default=4)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--variants", default="n2d0,n3d0,n4d0,n2d1,n3d1,n4d1")
+    ap.add_argument("--emit", default="")
+    a = ap.parse_args()
+    import torch
+    import neilpy_amd
+    from neilpy_amd import _lib
+    lib = _lib.load()
+    n = a.size
+    np_dt = np.float32 if a.dtype == "f32" else np.float64
+    Z = torch.from_numpy(neilpy_amd.synth_dem(n, seed=20240, dtype=np_dt)).cuda()
+    elem = Z.element_size()
+    nbytes = lib.smrf_progressive_filter_workspace_bytes(n, n, elem)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    mask = torch.empty((n, n), dtype=torch.uint8, device="cuda")
+    ref = getattr(lib, "smrf_progressive_filter_" + a.dtype)
+    vdir = os.path.join(os.path.dirname(_lib.__file__), "_lib", "variants")
+    fns = {}
+    for v in a.variants.split(","):
+        o = C.CDLL(os.path.join(vdir, v + ".so"))
+        f = getattr(o, "smrf_progressive_filter_" + a.dtype)
+        f.restype, f.argtypes = ref.restype, ref.argtypes
+        fns[v] = f
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    table, total = {}, {v: 0.0 for v in fns}
+    best_total = 0.0
+    for r in range(1, a.rmax + 1):
+        win = np.array([r], dtype=np.int32)
+        thr = np.array([.15 * r], dtype=np.float64)
+        ts = {v: [] for v in fns}
+        sums = {}
+        for i in range(a.reps + 1):
+            for v, fn in fns.items():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = fn(C.c_void_p(Z.data_ptr()), n, n, win.ctypes.data_as(C.c_void_p), thr.ctypes.data_as(C.c_void_p), 1,
+                        C.c_void_p(mask.data_ptr()), None, C.c_void_p(ws.data_ptr()), nbytes, 0, 0, st)
+                assert rc == 0, rc
+                e1.record()
+                torch.cuda.synchronize()
+                if i:
+                    ts[v].append(e0.elapsed_time(e1))
+                elif r % 8 == 1:
+                    sums[v] = int(mask.sum().item())
+        assert len(set(sums.values())) <= 1, sums          # every build flags the same cells
+        med = {v: float(np.median(t)) for v, t in ts.items()}
+        best = min(med, key=med.get)
+        first = list(fns)[0]
+        # keep the default build unless another one is at least 1% faster
+        if med[first] <= med[best] * 1.01:
+            best = first
+        m = re.match(r"n(\d)d(\d)", best)
+        table[r] = dict(variant=best, np_max=int(m.group(1)), occ_drop=int(m.group(2)), ms=med)
+        for v in fns:
+            total[v] += med[v]
+        best_total += med[best]
+        print("r=%2d  %s  -> %s" % (r, "  ".join("%s %.3f" % (v, med[v]) for v in fns), best), flush=True)
+    print("sum over radii 1..%d: %s | tuned %.2f ms" % (a.rmax, "  ".join("%s %.2f" % (v, t) for v, t in total.items()), best_total))
+    s50 = {v: sum(table[r]["ms"][v] for r in range(1, min(50, a.rmax) + 1)) for v in fns}
+    print("sum over radii 1..50: %s | tuned %.2f ms" % ("  ".join("%s %.2f" % (v, t) for v, t in s50.items()),
+          sum(table[r]["ms"][table[r]["variant"]] for r in range(1, min(50, a.rmax) + 1))))
+    print("np_max: {0, %s}" % ", ".join(str(table[r]["np_max"]) for r in range(1, a.rmax + 1)))
+    print("occ_drop: {0, %s}" % ", ".join(str(table[r]["occ_drop"]) for r in range(1, a.rmax + 1)))
+    if a.emit:
+        json.dump(table, open(a.emit, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
