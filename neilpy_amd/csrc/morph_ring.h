@@ -32,10 +32,10 @@
 #ifndef SMRF_RING_DEPTH
 #define SMRF_RING_DEPTH(need) 2   /* measured: a third group in flight gains nothing (lookups are not the exposed latency) */
 #endif
-// lookups per pipelined group: 4, or 2 where the 16 VGPRs saved keep a third wave per SIMD
-// (ring + window registers between 116 and 132 in fp32)
+// lookups per pipelined group: 4 for the small disks; 2 or 3 for the large ones, whose ring leaves
+// few registers for lookups in flight (measured per radius: tools/ring_tune.py --variants cur,g2,g3,g6)
 #ifndef SMRF_RING_G
-#define SMRF_RING_G(ringregs) (((ringregs) > 116 && (ringregs) <= 132) ? 2 : 4)
+#define SMRF_RING_G(ringregs) ((ringregs) > 132 ? 3 : (ringregs) > 100 ? 2 : 4)
 #endif
 // tuning builds (-DSMRF_RING_NO_TUNE): most row pairs per batch the chooser ring_np() may pick
 // (fp32; fp64 cells are twice as large: half) for every radius; product builds read ring_tune.inc
@@ -613,20 +613,28 @@ int ring_launch(const DiskArgs<T>& a_in, hipStream_t stream) {
   constexpr int NP = SMRF_RING_NP(T, R);
   using C = RingCfg<T, R, TW, NP>;
   auto kern = ring_kernel<T, R, DIL, TW, NP>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static int resident = 0;                               // workgroups one CU really holds (registers + LDS)
+  if (resident == 0) {
     if (C::LDS_BYTES > 48 * 1024)
       SMRF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
-    attr_done = true;
+    int nb = 0;
+    SMRF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), TW,
+                                                              C::LDS_BYTES));
+    resident = std::max(1, nb);
+    if (smrf_env_int("SMRF_RING_DEBUG", 0))
+      fprintf(stderr, "smrf ring: R=%d %s%s NP=%d G=%d LDS=%zu built for %d waves/SIMD, %d workgroups/CU resident\n", R,
+              sizeof(T) == 4 ? "f32" : "f64", DIL ? " dilate" : " erode", NP, C::G, C::LDS_BYTES, C::OCC, resident);
   }
   DiskArgs<T> a = a_in;
   const int strips = (a.cols + TW - 1) / TW;
   if (a.seg <= 0) {
-    // output rows per workgroup: about `rounds` full waves of resident workgroups (OCC per CU on
-    // 256 CUs), but segments long enough that the 2R halo rows each one re-reads stay a small part
-    const int rounds = smrf_env_int("SMRF_RING_ROUNDS", 2);
-    const int nseg = std::max(1, (rounds * C::WG_PER_CU * 256 + strips / 2) / strips);
+    // output rows per workgroup: `rounds` workgroups per resident slot of the 256 CUs.  One round
+    // (every workgroup resident at once, the longest segments, the fewest re-read halo rows) is
+    // the fastest from radius 20 up and as fast as any below (tools/ring_tune.py cur@SMRF_RING_ROUNDS=n);
+    // segments stay long enough that the 2R halo rows each one re-reads are a small part
+    const int rounds = smrf_env_int("SMRF_RING_ROUNDS", 1);
+    const int nseg = std::max(1, (rounds * resident * 256 + strips / 2) / strips);
     int seg = (a.out_rows + nseg - 1) / nseg;
     seg = std::max(seg, std::max(32, 4 * R));
     seg = std::min(seg, a.out_rows);

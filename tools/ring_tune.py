@@ -45,6 +45,9 @@ def main():
     vdir = os.path.join(os.path.dirname(_lib.__file__), "_lib", "variants")
     fns = {}
     for v in a.variants.split(","):
+        if v.startswith("cur"):                             # the product library itself, or cur@ENV=value
+            fns[v] = ref
+            continue
         o = C.CDLL(os.path.join(vdir, v + ".so"))
         f = getattr(o, "smrf_progressive_filter_" + a.dtype)
         f.restype, f.argtypes = ref.restype, ref.argtypes
@@ -60,12 +63,17 @@ def main():
         for i in range(a.reps + 1):
             for v, fn in fns.items():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                if "@" in v:
+                    key, val = v.split("@")[1].split("=")
+                    os.environ[key] = val
                 e0.record()
                 rc = fn(C.c_void_p(Z.data_ptr()), n, n, win.ctypes.data_as(C.c_void_p), thr.ctypes.data_as(C.c_void_p), 1,
                         C.c_void_p(mask.data_ptr()), None, C.c_void_p(ws.data_ptr()), nbytes, 0, 0, st)
                 assert rc == 0, rc
                 e1.record()
                 torch.cuda.synchronize()
+                if "@" in v:
+                    del os.environ[key]
                 if i:
                     ts[v].append(e0.elapsed_time(e1))
                 elif r % 8 == 1:
@@ -78,7 +86,7 @@ def main():
         if med[first] <= med[best] * 1.01:
             best = first
         m = re.match(r"n(\d)d(\d)", best)
-        table[r] = dict(variant=best, np_max=int(m.group(1)), occ_drop=int(m.group(2)), ms=med)
+        table[r] = dict(variant=best, np_max=int(m.group(1)) if m else -1, occ_drop=int(m.group(2)) if m else -1, ms=med)
         for v in fns:
             total[v] += med[v]
         best_total += med[best]
