@@ -17,6 +17,7 @@
  *   smrf_springs_lsqr_f64     inpaint_nans_by_springs(), neilpy/neilpy.py:1227-1271, whose
  *                             solve is scipy.sparse.linalg.lsqr (:1264)
  *   smrf_gradient_slope_f64   np.gradient + sqrt, neilpy/neilpy.py:1785-1786
+ *   smrf_pssm_f64             pssm(), neilpy/neilpy.py:846-867
  *   smrf_las_decode_xyz_f64   the coordinate decode of read_las(), neilpy/neilpy.py:903-1087 (host
  *                             side: neilpy_amd/las.py)
  *   smrf_spline_solve_f64, smrf_spline_eval_f64, smrf_classify_points_f64
@@ -204,6 +205,13 @@ SMRF_API int smrf_springs_band_status(const void* d_workspace, int rows_local, i
  * first-order one-sided edges).  rows, cols >= 2. */
 SMRF_API int smrf_gradient_slope_f64(const double* d_Z, double* d_S, int rows, int cols, double cellsize,
                             void* stream);
+
+/* pssm(), neilpy/neilpy.py:846-867 (the bonemaps of examples/smrf/ *.ipynb): slope as above, then
+ * P = uint8(round(255 * (rad2deg(arctan(ve * S)) / 90))) into d_P (rows x cols, nullable) and, when
+ * d_rgba is given, the colormap lookup d_rgba[i][0..3] = d_lut[P[i]][0..3] (d_lut: 256 x 4 doubles,
+ * what plt.cm.bone_r / plt.cm.bone hold; d_rgba: rows x cols x 4 doubles). */
+SMRF_API int smrf_pssm_f64(const double* d_Z, uint8_t* d_P, double* d_rgba, const double* d_lut, int rows, int cols,
+                  double cellsize, double ve, void* stream);
 
 /* Interpolating bicubic spline of scipy.interpolate.RectBivariateSpline(rows, cols, Z) with its
  * defaults kx = ky = 3, s = 0 (neilpy.py:1773, :1788): d_C holds the raster on entry and the

@@ -6,9 +6,9 @@ in hand-written gfx950 HIP kernels in ``libsmrf_hip.so`` (C ABI: ``include/smrf_
 there is no CPU fallback.
 """
 from ._lib import SmrfHipError, load as load_library, LIB_PATH          # noqa: F401
-from .affine import Affine, from_origin                                  # noqa: F401
+from .affine import Affine, from_origin, write_worldfile                 # noqa: F401
 from .api import (create_dem, dilation, disk, erosion, inpaint_nans_by_springs, last_stats,   # noqa: F401
-                  opening, progressive_filter, smrf)
+                  opening, progressive_filter, pssm, smrf)
 from .las import read_las, read_las_xyz, write_las                         # noqa: F401
 from .synth import synth_dem, synth_points                               # noqa: F401
 

@@ -52,6 +52,7 @@ SIGNATURES = {
     "smrf_springs_band_phase": (_i, [_i, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "smrf_springs_band_status": (_i, [_p, _i, _i, C.POINTER(_i), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i), _p]),
     "smrf_gradient_slope_f64": (_i, [_p, _p, _i, _i, _d, _p]),
+    "smrf_pssm_f64": (_i, [_p, _p, _p, _p, _i, _i, _d, _d, _p]),
     "smrf_spline_solve_f64": (_i, [_p, _i, _i, _p, _p, _p]),
     "smrf_spline_eval_f64": (_i, [_p, _i, _i, _p, _p, _p, _p, _i64, _p, _p]),
     "smrf_classify_points_f64": (_i, [_p, _p, _p, _i64, _d, _d, _p, _p]),

@@ -52,3 +52,16 @@ def from_origin(west, north, xsize, ysize):
     if _ExternalAffine is not None:
         return _ExternalAffine.translation(west, north) * _ExternalAffine.scale(xsize, -ysize)
     return Affine(1.0, 0.0, west, 0.0, 1.0, north) * Affine(xsize, 0.0, 0.0, 0.0, -ysize, 0.0)
+
+
+def write_worldfile(affine_matrix, output_file):
+    """neilpy.write_worldfile (neilpy/neilpy.py:1564-1570): the six world-file lines (pixel width,
+    column rotation, row rotation, pixel height, x and y of the centre of the upper-left pixel),
+    ``%0.10f`` each, for the rasters ``pssm`` / ``smrf`` return with transform ``affine_matrix``."""
+    x_ul_center, y_ul_center = affine_matrix * (.5, .5)
+    pixel_width, row_rotation = affine_matrix[0], affine_matrix[1]
+    pixel_height, col_rotation = affine_matrix[4], affine_matrix[3]
+    world = [pixel_width, col_rotation, row_rotation, pixel_height, x_ul_center, y_ul_center]
+    with open(output_file, "w") as fh:
+        for v in world:
+            fh.write("%0.10f\n" % v)

@@ -2,8 +2,8 @@
 
 Mirrors, argument for argument, the reference functions (paths relative to the reference
 checkout): ``create_dem`` (neilpy/neilpy.py:1110), ``inpaint_nans_by_springs`` (:1227),
-``progressive_filter`` (:1659), ``smrf`` (:1685) and the skimage seam they use, ``disk`` /
-``opening`` (:43-44, :1670).  Build-specific options are keyword-only and come last.
+``progressive_filter`` (:1659), ``smrf`` (:1685), the skimage seam they use, ``disk`` /
+``opening`` (:43-44, :1670), and the notebooks' shading step ``pssm`` (:846).  Build-specific options are keyword-only and come last.
 
 NumPy in -> NumPy out; ``torch`` CUDA tensor in -> CUDA tensor out (no host copy).  All compute
 runs in hand-written HIP kernels behind the C ABI of ``include/smrf_hip.h``; PyTorch only owns
@@ -18,7 +18,7 @@ from . import _lib
 from .affine import from_origin
 
 __all__ = ["disk", "erosion", "dilation", "opening", "progressive_filter", "create_dem",
-           "inpaint_nans_by_springs", "smrf", "last_stats"]
+           "inpaint_nans_by_springs", "smrf", "pssm", "last_stats"]
 
 #: statistics of the most recent calls (LSQR istop / itn, unknown counts), SURVEY section 5
 last_stats = {}
@@ -387,3 +387,44 @@ def smrf(x, y, z, cellsize=1, windows=5, slope_threshold=.15, elevation_threshol
     extras = {'above_ground_height': zh - elevation_values, 'drop_raster': drop_raster,
               'when_dropped': drop_raster[np.round(r).astype(int), np.round(c).astype(int)]}
     return Zpro, t, obj_np, is_object_point, extras
+
+
+# ------------------------------------------------------------------------------------------
+# pssm  (neilpy.py:846-867) - the bonemaps of examples/smrf/*.ipynb
+# ------------------------------------------------------------------------------------------
+_lut_cache = {}
+
+
+def pssm(Z, cellsize=1, ve=2.3, reverse=False, apply_colormap=True):
+    """Perceptually scaled slope map, same arguments and results as neilpy.pssm.
+
+    ``apply_colormap=True``: float64 RGBA raster ``(rows, cols, 4)`` looked up in the bone
+    colormap (``bone_r`` unless ``reverse``); ``False``: the uint8 slope classes
+    ``round(255 * degrees(arctan(ve * slope)) / 90)``.  One fused kernel (gradient, slope, class,
+    colour).  The arithmetic is float64 (a float32 or integer raster is widened first; the
+    reference keeps float32 rasters in float32, which can move a class by one at a rounding tie).
+    """
+    torch = _torch()
+    was_tensor = _is_tensor(Z)
+    Zd = _to_device(Z, torch.float64)
+    if Zd.dim() != 2:
+        raise ValueError("expected a 2-D raster")
+    rows, cols = Zd.shape
+    if rows < 2 or cols < 2:
+        raise ValueError("Shape of array too small to calculate a numerical gradient, "
+                         "at least (edge_order + 1) elements are required.")      # np.gradient's message
+    lib = _lib.load()
+    P = rgba = lut = None
+    if apply_colormap:
+        key = (bool(reverse), Zd.device.index)
+        if key not in _lut_cache:
+            from .colormap import bone_lut
+            _lut_cache[key] = torch.from_numpy(np.array(bone_lut(reverse=not reverse))).to(Zd.device)
+        lut = _lut_cache[key]
+        rgba = torch.empty((rows, cols, 4), dtype=torch.float64, device=Zd.device)
+    else:
+        P = torch.empty((rows, cols), dtype=torch.uint8, device=Zd.device)
+    _lib.check(lib.smrf_pssm_f64(_ptr(Zd), _ptr(P), _ptr(rgba), _ptr(lut), rows, cols, float(cellsize), float(ve),
+                                 _stream()))
+    out = rgba if apply_colormap else P
+    return out if was_tensor else out.cpu().numpy()

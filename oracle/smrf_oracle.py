@@ -367,3 +367,21 @@ def smrf(x, y, z, cellsize=1, windows=5, slope_threshold=.15, elevation_threshol
     if return_stages:
         out = out + (stages,)
     return out
+
+
+def pssm_classes(Z, cellsize=1, ve=2.3):                                # neilpy/neilpy.py:846-858
+    """uint8 slope classes of pssm(): gradient, slope, vertical exaggeration, degrees / 90, x255, round."""
+    gy, gx = np.gradient(Z, cellsize)
+    S = np.sqrt(gx ** 2 + gy ** 2)
+    P = np.rad2deg(np.arctan(ve * S)) / 90
+    return np.round(255 * P).astype(np.uint8)
+
+
+def pssm(Z, lut, cellsize=1, ve=2.3):                                   # neilpy/neilpy.py:860-865
+    """``lut``: the 256 x 4 table of the colormap (matplotlib indexes it with the integer image)."""
+    return np.asarray(lut)[pssm_classes(Z, cellsize, ve)]
+
+
+def worldfile_lines(t):                                                 # neilpy/neilpy.py:1564-1570
+    x_ul, y_ul = t * (.5, .5)
+    return ["%0.10f" % v for v in (t[0], t[3], t[1], t[4], x_ul, y_ul)]

@@ -476,11 +476,51 @@ def golden_las(ref, out):
     np.savez_compressed(os.path.join(out, "las.npz"), **res)
 
 
+def golden_pssm(ref, out):
+    """pssm() classes and bonemaps, and write_worldfile() text, from the reference itself."""
+    import tempfile
+    rng = np.random.default_rng(4711)
+    yy, xx = np.mgrid[0:97, 0:83].astype(np.float64)
+    hills = 30 * np.sin(xx / 9.0) * np.cos(yy / 13.0) + 0.2 * xx + rng.normal(0, 0.05, xx.shape)
+    flat = hills.copy()
+    flat[20:50, 10:60] = 12.5                                        # a plateau: slope exactly 0
+    cases = {
+        "hills_c1": (hills, 1, 2.3),
+        "hills_c5_ve1": (hills, 5, 1.0),
+        "steep": (rng.uniform(0, 500, (40, 33)), 0.5, 2.3),
+        "plateau_c2": (flat, 2, 2.3),
+        "tiny": (np.array([[1.0, 2.5], [0.25, 7.0]]), 1, 2.3),
+        "strip": (np.cumsum(rng.normal(0, 1, (2, 57)), axis=1), 1, 4.0),
+    }
+    res = {"cases": np.array(sorted(cases))}
+    for name, (Z, cellsize, ve) in cases.items():
+        res[name + "_Z"] = Z
+        res[name + "_args"] = np.array([cellsize, ve], dtype=np.float64)
+        res[name + "_P"] = ref.pssm(Z.copy(), cellsize=cellsize, ve=ve, apply_colormap=False)
+        print("pssm", name, Z.shape, int(res[name + "_P"].max()), flush=True)
+    res["hills_c1_rgba"] = ref.pssm(hills.copy(), cellsize=1)
+    res["hills_c1_rgba_reverse"] = ref.pssm(hills.copy(), cellsize=1, reverse=True)
+    idx = np.arange(256, dtype=np.uint8)
+    res["lut_bone_r"] = ref.plt.cm.bone_r(idx)                        # what reverse=False looks up
+    res["lut_bone"] = ref.plt.cm.bone(idx)
+    world = []
+    for args in ((512699.5, 5403850.5, 1, 1), (1709001.45, 18012834.55, .3, .3), (-73.25, 41.125, 5, 5)):
+        t = ref.rasterio.transform.from_origin(*args)
+        with tempfile.NamedTemporaryFile("r", suffix=".pgw") as fh:
+            ref.write_worldfile(t, fh.name)
+            world.append(json.dumps(dict(origin=list(args), lines=open(fh.name).read().split())))
+    res["worldfiles"] = np.array(world)
+    np.savez_compressed(os.path.join(out, "pssm.npz"), **res)
+
+
 def main():
     out = HERE
     ref = import_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "las":
         golden_las(ref, out)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "pssm":
+        golden_pssm(ref, out)
         return
     rec = Recorder(ref)
     golden_samples(out)
@@ -488,6 +528,7 @@ def main():
     golden_inpaint(ref, rec, out)
     golden_create_dem(ref, rec, out)
     golden_las(ref, out)
+    golden_pssm(ref, out)
     anchors, published = golden_smrf(ref, rec, out)
     meta = dict(
         generated_by="tests/golden/make_golden.py (reference imported from /root/reference)",
