@@ -16,6 +16,7 @@
  *                             at :1151-1156, affine index arithmetic at :1141-1143)
  *   smrf_springs_lsqr_f64     inpaint_nans_by_springs(), neilpy/neilpy.py:1227-1271, whose
  *                             solve is scipy.sparse.linalg.lsqr (:1264)
+ *   smrf_fda_lsqr_f64         inpaint_nans_by_fda(), neilpy/neilpy.py:1170-1216
  *   smrf_gradient_slope_f64   np.gradient + sqrt, neilpy/neilpy.py:1785-1786
  *   smrf_pssm_f64             pssm(), neilpy/neilpy.py:846-867
  *   smrf_las_decode_xyz_f64   the coordinate decode of read_las(), neilpy/neilpy.py:903-1087 (host
@@ -197,6 +198,16 @@ SMRF_API int smrf_springs_band_phase(int phase, double* d_A_band, int rows_local
                             int has_below, void* d_workspace, size_t workspace_bytes, void* stream);
 SMRF_API int smrf_springs_band_status(const void* d_workspace, int rows_local, int cols, int* h_istop,
                              int64_t* h_itn, int64_t* h_n_unknown, int* h_done, void* stream);
+
+/* inpaint_nans_by_fda(A), neilpy/neilpy.py:1170-1216: the NaN cells of d_A (rows x cols, float64,
+ * C order) are replaced in place by scipy.sparse.linalg.lsqr's iterate on the second-difference
+ * equations that touch a NaN cell, every equation weighted by its number of NaN stencil cells
+ * as the reference's row selection does (:1207-1210).  Arguments as smrf_springs_lsqr_f64.
+ * Single device. */
+SMRF_API size_t smrf_fda_workspace_bytes(int rows, int cols);
+SMRF_API int smrf_fda_lsqr_f64(double* d_A, int rows, int cols, double atol, double btol, double conlim,
+                      int64_t iter_lim, int* h_istop, int64_t* h_itn, int64_t* h_n_unknown,
+                      void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * smrf tail

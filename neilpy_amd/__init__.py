@@ -7,7 +7,8 @@ there is no CPU fallback.
 """
 from ._lib import SmrfHipError, load as load_library, LIB_PATH          # noqa: F401
 from .affine import Affine, from_origin, write_worldfile                 # noqa: F401
-from .api import (create_dem, dilation, disk, erosion, inpaint_nans_by_springs, last_stats,   # noqa: F401
+from .api import (create_dem, dilation, disk, erosion, inpaint_nans_by_fda, inpaint_nans_by_springs,   # noqa: F401
+                  last_stats,
                   opening, progressive_filter, pssm, smrf)
 from .las import read_las, read_las_xyz, write_las                         # noqa: F401
 from .synth import synth_dem, synth_points                               # noqa: F401

@@ -46,6 +46,9 @@ SIGNATURES = {
     "smrf_springs_workspace_bytes": (_sz, [_i, _i]),
     "smrf_springs_lsqr_f64": (_i, [_p, _i, _i, _d, _d, _d, _i64, C.POINTER(_i), C.POINTER(_i64),
                                    C.POINTER(_i64), _p, _sz, _p]),
+    "smrf_fda_workspace_bytes": (_sz, [_i, _i]),
+    "smrf_fda_lsqr_f64": (_i, [_p, _i, _i, _d, _d, _d, _i64, C.POINTER(_i), C.POINTER(_i64),
+                               C.POINTER(_i64), _p, _sz, _p]),
     "smrf_springs_band_workspace_bytes": (_sz, [_i, _i]),
     "smrf_springs_band_layout": (_i, [_i, _i, C.POINTER(_i64)]),
     "smrf_springs_band_begin": (_i, [_i, _i, _d, _d, _d, _i64, _p, _sz, _p]),

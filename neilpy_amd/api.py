@@ -2,7 +2,7 @@
 
 Mirrors, argument for argument, the reference functions (paths relative to the reference
 checkout): ``create_dem`` (neilpy/neilpy.py:1110), ``inpaint_nans_by_springs`` (:1227),
-``progressive_filter`` (:1659), ``smrf`` (:1685), the skimage seam they use, ``disk`` /
+``inpaint_nans_by_fda`` (:1170), ``progressive_filter`` (:1659), ``smrf`` (:1685), the skimage seam they use, ``disk`` /
 ``opening`` (:43-44, :1670), and the notebooks' shading step ``pssm`` (:846).  Build-specific options are keyword-only and come last.
 
 NumPy in -> NumPy out; ``torch`` CUDA tensor in -> CUDA tensor out (no host copy).  All compute
@@ -18,7 +18,7 @@ from . import _lib
 from .affine import from_origin
 
 __all__ = ["disk", "erosion", "dilation", "opening", "progressive_filter", "create_dem",
-           "inpaint_nans_by_springs", "smrf", "pssm", "last_stats"]
+           "inpaint_nans_by_springs", "inpaint_nans_by_fda", "smrf", "pssm", "last_stats"]
 
 #: statistics of the most recent calls (LSQR istop / itn, unknown counts), SURVEY section 5
 last_stats = {}
@@ -303,6 +303,59 @@ def inpaint_nans_by_springs(A, inplace=False, neighbors=4):
         A[...] = out
         return None
     return out.astype(arr.dtype, copy=False) if arr.dtype == np.float64 else out
+
+
+# ------------------------------------------------------------------------------------------
+# inpaint_nans_by_fda  (neilpy.py:1170-1216)
+# ------------------------------------------------------------------------------------------
+def _fda_device(Ad, key="inpaint_fda"):
+    """In-place LSQR finite-difference fill of a contiguous float64 CUDA raster; returns (istop, itn)."""
+    torch = _torch()
+    lib = _lib.load()
+    rows, cols = Ad.shape
+    if rows == 0 or cols == 0:
+        return 0, 0
+    nbytes = lib.smrf_fda_workspace_bytes(rows, cols)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=Ad.device)
+    istop, itn, nunk = C.c_int(0), C.c_int64(0), C.c_int64(0)
+    _lib.check(lib.smrf_fda_lsqr_f64(_ptr(Ad), rows, cols, 1e-6, 1e-6, 1e8, -1, C.byref(istop), C.byref(itn),
+                                     C.byref(nunk), _ptr(ws), nbytes, _stream()))
+    last_stats[key] = dict(istop=istop.value, itn=itn.value, n_unknown=nunk.value)
+    return istop.value, itn.value
+
+
+def inpaint_nans_by_fda(A, fast=True, inplace=False):
+    """Fill NaNs by least squares on the second-difference equations, stopped where SciPy's LSQR stops.
+
+    Same arguments and results as neilpy.inpaint_nans_by_fda.  ``fast`` only pre-filters equations
+    that cannot touch a NaN in the reference, so both settings give the same raster (and run the
+    same kernels here).  ``inplace=True`` writes into ``A`` and returns ``None``.
+    """
+    torch = _torch()
+    if _is_tensor(A):
+        if A.dtype != torch.float64:
+            raise TypeError("inpaint_nans_by_fda works in float64")
+        if A.dim() != 2 or A.shape[0] < 2 or A.shape[1] < 2:
+            raise ValueError("negative dimensions are not allowed")
+        work = A if (inplace and A.is_cuda and A.is_contiguous()) else _to_device(A).clone()
+        _fda_device(work)
+        if inplace:
+            if work is not A:
+                A.copy_(work)
+            return None
+        return work
+    arr = np.asarray(A)
+    if arr.ndim != 2:
+        raise ValueError("expected a 2-D raster")
+    if arr.shape[0] < 2 or arr.shape[1] < 2:
+        raise ValueError("negative dimensions are not allowed")      # the reference's np.ones(2*n*(m-2)) at :1190
+    work = _to_device(arr.astype(np.float64, copy=False), torch.float64).clone()
+    _fda_device(work)
+    out = work.cpu().numpy()
+    if inplace:
+        A[...] = out
+        return None
+    return out
 
 
 # ------------------------------------------------------------------------------------------

@@ -21,23 +21,9 @@
 // single-device solver is the same kernels on a band that is the whole raster.
 // Reductions are two-stage with a fixed tree (no float atomics): results are reproducible.
 // HBM-bound: per iteration about 3 plane reads + 2 plane writes of each of u (2 planes), v, w, x.
-#include <algorithm>
-#include <cmath>
-
-#include "smrf_common.h"
+#include "lsqr_core.h"
 
 namespace {
-
-constexpr int MAXB = 1024;   // partial sums per reduction
-
-struct Sc {
-  double alfa, beta, inv_alfa, inv_beta;
-  double rhobar, phibar, bnorm, anorm, ddnorm, xxnorm, z, cs2, sn2;
-  double t1, t2, inv_rho, xnorm, tau;
-  double atol, btol, ctol;
-  long long itn, iter_lim, nunk;
-  int istop, done, beta_pos, pad;
-};
 
 // One row band of the raster.  Plane pointers address the first OWN row; row -1 and row `rows` are
 // halo rows (allocated always, meaningful only where has_above / has_below).
@@ -50,33 +36,6 @@ struct Band {
   Sc* sc;
   int rows, cols, has_above, has_below;
 };
-
-// 2-D walk over the band's cells without an integer division per cell: blockIdx.x picks 256 columns,
-// blockIdx.y strides over the rows.  Defines r, c and the flat index i.
-#define SMRF_FOR_CELLS(rows_, cols_)                                                        \
-  for (int r = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x; r < (rows_); r += gridDim.y) \
-    for (long long i = (long long)r * (cols_) + c; c < (cols_) && i >= 0; i = -1)
-
-__device__ __forceinline__ double block_sum(double s, double* red) {
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-  const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) red[w] = s;
-  __syncthreads();
-  double t = 0.0;
-  if (threadIdx.x == 0) t = ((red[0] + red[1]) + (red[2] + red[3]));
-  return t;   // valid on thread 0
-}
-
-__device__ __forceinline__ bool stopped(const Sc* sc) { return sc->done != 0 || sc->istop != 0; }
-
-// block partials -> red[0]
-__global__ __launch_bounds__(256) void reduce_kernel(const double* __restrict__ part, int nb, double* __restrict__ out) {
-  __shared__ double red[4];
-  double s = 0.0;
-  for (int i = threadIdx.x; i < nb; i += 256) s += part[i];
-  const double t = block_sum(s, red);
-  if (threadIdx.x == 0) out[0] = t;
-}
 
 // ---- setup ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mask_kernel(const double* __restrict__ A, const Band b) {
@@ -215,60 +174,11 @@ __global__ __launch_bounds__(256) void av_kernel(const Band b) {
   if (threadIdx.x == 0) b.part[blockIdx.y * gridDim.x + blockIdx.x] = t;
 }
 
-__device__ void beta_step(Sc* sc, double sum_u) {
-  const double bt = sqrt(sum_u);
-  sc->beta = bt;
-  sc->beta_pos = bt > 0;
-  if (bt > 0) {
-    sc->inv_beta = 1 / bt;
-    sc->anorm = sqrt(sc->anorm * sc->anorm + sc->alfa * sc->alfa + bt * bt);
-  } else {
-    sc->inv_beta = 1.0;   // scipy leaves u unscaled when beta == 0
-  }
-}
 __global__ void s_beta(const Band b) {
   if (stopped(b.sc)) return;
   beta_step(b.sc, b.red[0]);
 }
 
-__device__ __forceinline__ double sgn(double a) { return a > 0 ? 1.0 : (a < 0 ? -1.0 : 0.0); }
-
-__device__ void alfa_rot_step(Sc* sc, double sum_v) {
-  if (sc->beta_pos) {
-    const double a = sqrt(sum_v);
-    sc->alfa = a;
-    sc->inv_alfa = a > 0 ? 1 / a : 1.0;
-  }
-  const double alfa = sc->alfa, beta = sc->beta;
-  // cs, sn, rho = _sym_ortho(rhobar, beta)   (lsqr.py:62-94)
-  const double a = sc->rhobar, b = beta;
-  double cs, sn, rho;
-  if (b == 0) { cs = sgn(a); sn = 0; rho = fabs(a); }
-  else if (a == 0) { cs = 0; sn = sgn(b); rho = fabs(b); }
-  else if (fabs(b) > fabs(a)) { const double tau = a / b; sn = sgn(b) / sqrt(1 + tau * tau); cs = sn * tau; rho = b / sn; }
-  else { const double tau = b / a; cs = sgn(a) / sqrt(1 + tau * tau); sn = cs * tau; rho = a / cs; }
-  const double theta = sn * alfa;
-  sc->rhobar = -cs * alfa;
-  const double phi = cs * sc->phibar;
-  sc->phibar = sn * sc->phibar;
-  const double tau = sn * phi;
-  sc->t1 = phi / rho;
-  sc->t2 = -theta / rho;
-  sc->inv_rho = 1 / rho;
-  // the norm(x) estimate (lsqr.py:474-483)
-  const double delta = sc->sn2 * rho;
-  const double gambar = -sc->cs2 * rho;
-  const double rhs = phi - delta * sc->z;
-  const double zbar = rhs / gambar;
-  const double xnorm = sqrt(sc->xxnorm + zbar * zbar);
-  const double gamma = sqrt(gambar * gambar + theta * theta);
-  sc->cs2 = gambar / gamma;
-  sc->sn2 = theta / gamma;
-  sc->z = rhs / gamma;
-  sc->xxnorm = sc->xxnorm + sc->z * sc->z;
-  sc->xnorm = xnorm;   // for the stopping tests
-  sc->tau = tau;
-}
 __global__ void s_alfa_rot(const Band b) {
   if (stopped(b.sc)) return;
   alfa_rot_step(b.sc, b.red[0]);
@@ -294,31 +204,6 @@ __global__ __launch_bounds__(256) void xw_kernel(const Band b) {
   if (threadIdx.x == 0) b.part[blockIdx.y * gridDim.x + blockIdx.x] = t;
 }
 
-__device__ void tests_step(Sc* sc, double sum_dk) {
-  const double EPS = 2.220446049250313e-16;
-  const double xnorm = sc->xnorm, tau = sc->tau;
-  const double nd = sqrt(sum_dk);
-  sc->ddnorm = sc->ddnorm + nd * nd;
-  sc->itn += 1;
-  const double anorm = sc->anorm, bnorm = sc->bnorm;
-  const double acond = anorm * sqrt(sc->ddnorm);
-  const double rnorm = sqrt(sc->phibar * sc->phibar);
-  const double arnorm = sc->alfa * fabs(tau);
-  const double test1 = rnorm / bnorm;
-  const double test2 = arnorm / (anorm * rnorm + EPS);
-  const double test3 = 1 / (acond + EPS);
-  const double t1 = test1 / (1 + anorm * xnorm / bnorm);
-  const double rtol = sc->btol + sc->atol * anorm * xnorm / bnorm;
-  int istop = 0;
-  if (sc->itn >= sc->iter_lim) istop = 7;
-  if (1 + test3 <= 1) istop = 6;
-  if (1 + test2 <= 1) istop = 5;
-  if (1 + t1 <= 1) istop = 4;
-  if (test3 <= sc->ctol) istop = 3;
-  if (test2 <= sc->atol) istop = 2;
-  if (test1 <= rtol) istop = 1;
-  sc->istop = istop;
-}
 __global__ void s_tests(const Band b) {
   if (stopped(b.sc)) return;
   tests_step(b.sc, b.red[0]);
@@ -365,31 +250,6 @@ __global__ __launch_bounds__(256) void xwav_kernel(const Band b) {
   const double tu = block_sum(su, red2);
   if (threadIdx.x == 0) { b.part[blockIdx.y * gridDim.x + blockIdx.x] = td; b.part[MAXB + blockIdx.y * gridDim.x + blockIdx.x] = tu; }
 }
-
-// reduce the block partials and run the scalar step(s) in the same launch (one block)
-template <int WHAT>   // 0: beta   1: alfa + rotation   2: tests(i) then beta(i+1)
-__global__ __launch_bounds__(256) void reduce_scalar_kernel(const Band b, int nb) {
-  __shared__ double red[4];
-  __shared__ double red2[4];
-  Sc* sc = b.sc;
-  if (stopped(sc)) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int i = threadIdx.x; i < nb; i += 256) {
-    s0 += b.part[i];
-    if (WHAT == 2) s1 += b.part[MAXB + i];
-  }
-  const double t0 = block_sum(s0, red);
-  const double t1 = WHAT == 2 ? block_sum(s1, red2) : 0.0;
-  if (threadIdx.x == 0) {
-    if (WHAT == 0) beta_step(sc, t0);
-    if (WHAT == 1) alfa_rot_step(sc, t0);
-    if (WHAT == 2) {
-      tests_step(sc, t0);
-      if (sc->istop == 0) beta_step(sc, t1);
-    }
-  }
-}
-
 
 __global__ __launch_bounds__(256) void scatter_kernel(double* __restrict__ A, const Band b) {
   const long long n = (long long)b.rows * b.cols;
@@ -532,16 +392,16 @@ int smrf_springs_lsqr_f64(double* d_A, int rows, int cols, double atol, double b
   // Four launches per iteration: atu | reduce+alfa_rot | xw(i) fused with av(i+1) | reduce+tests(i)+beta(i+1).
   if (!out.done && out.istop == 0 && out.itn < lim) {
     hipLaunchKernelGGL(av_kernel, g2, dim3(256), 0, stream, b);
-    hipLaunchKernelGGL(reduce_scalar_kernel<0>, dim3(1), dim3(256), 0, stream, b, nb);
+    hipLaunchKernelGGL((reduce_scalar_kernel<0, Band>), dim3(1), dim3(256), 0, stream, b, nb);
     SMRF_LAUNCH_CHECK();
   }
   int chunk = 4;
   while (!out.done && out.istop == 0 && out.itn < lim) {
     for (int k = 0; k < chunk; ++k) {
       hipLaunchKernelGGL(atu_kernel, g2, dim3(256), 0, stream, b);
-      hipLaunchKernelGGL(reduce_scalar_kernel<1>, dim3(1), dim3(256), 0, stream, b, nb);
+      hipLaunchKernelGGL((reduce_scalar_kernel<1, Band>), dim3(1), dim3(256), 0, stream, b, nb);
       hipLaunchKernelGGL(xwav_kernel, g2, dim3(256), 0, stream, b);
-      hipLaunchKernelGGL(reduce_scalar_kernel<2>, dim3(1), dim3(256), 0, stream, b, nb);
+      hipLaunchKernelGGL((reduce_scalar_kernel<2, Band>), dim3(1), dim3(256), 0, stream, b, nb);
     }
     SMRF_LAUNCH_CHECK();
     SMRF_HIP_CHECK(hipMemcpyAsync(&out, b.sc, sizeof(out), hipMemcpyDeviceToHost, stream));

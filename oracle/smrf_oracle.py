@@ -25,6 +25,8 @@ Third-party arithmetic the reference reaches on this path and how it is restated
 * ``scipy.sparse.linalg.lsqr`` (SciPy 1.15.3 ``_isolve/lsqr.py:97-587``) ->
   :func:`lsqr_springs`, matrix-free on the raster's edge planes.
 * ``scipy.interpolate.RectBivariateSpline`` -> used as is (FITPACK).
+* ``inpaint_nans_by_fda`` (:1170-1216) -> :func:`fda_system` (own assembly of the
+  weighted second-difference equations) + SciPy's ``lsqr`` itself.
 """
 from math import sqrt
 
@@ -271,6 +273,47 @@ def inpaint_nans_by_springs(A, inplace=False, neighbors=4, return_info=False):
         A[...] = B
         return (None, istop, itn) if return_info else None
     return (B, istop, itn) if return_info else B
+
+
+# ----------------------------------------------------------------------------
+# inpaint_nans_by_fda (neilpy.py:1170-1216): assembled system, SciPy's own LSQR
+# ----------------------------------------------------------------------------
+def fda_system(A):
+    """(a, b, nan_list) of the least-squares problem the reference hands to LSQR.
+
+    One equation per raster cell: vertical [1, -2, 1] unless in the first/last row plus horizontal
+    [1, -2, 1] unless in the first/last column (:1180-1194; no equation at the four corners).  The
+    equations that touch a NaN cell are kept once per NaN entry (:1207-1209: ``nonzero()[0]`` of
+    the NaN columns lists a row once per stored entry); b = -(known columns) @ known values (:1206).
+    """
+    from scipy import sparse
+    m, n = A.shape
+    if m < 2 or n < 2:
+        raise ValueError("negative dimensions are not allowed")          # what np.ones(2*n*(m-2)) raises at :1190
+    flat = np.arange(m * n, dtype=np.int64).reshape(m, n)
+    inner_r, inner_c = flat[1:-1, :].ravel(), flat[:, 1:-1].ravel()
+    rows = np.concatenate([inner_r, inner_r, inner_r, inner_c, inner_c, inner_c])
+    cols = np.concatenate([inner_r - n, inner_r + n, inner_r, inner_c - 1, inner_c + 1, inner_c])
+    vals = np.concatenate([np.ones(2 * inner_r.size), -2 * np.ones(inner_r.size),
+                           np.ones(2 * inner_c.size), -2 * np.ones(inner_c.size)]).astype(np.int8)
+    L = sparse.coo_matrix((vals, (rows, cols)), (m * n, m * n), dtype=np.int8).tocsr()   # duplicates summed
+    nan = np.isnan(A).ravel()
+    nan_list, known = np.flatnonzero(nan), np.flatnonzero(~nan)
+    b = -L[:, known] * A.ravel()[known]
+    Ln = L[:, nan_list]
+    k = np.repeat(np.arange(m * n), np.diff(Ln.indptr))
+    return Ln[k], b[k], nan_list
+
+
+def inpaint_nans_by_fda(A, fast=True, inplace=False, return_info=False):
+    from scipy.sparse.linalg import lsqr
+    a, b, nan_list = fda_system(A)
+    res = lsqr(a, b)
+    B = A if inplace else A.copy()
+    B.ravel()[nan_list] = res[0]
+    if inplace:
+        return (None, res[1], res[2]) if return_info else None
+    return (B, res[1], res[2]) if return_info else B
 
 
 # ----------------------------------------------------------------------------

@@ -387,6 +387,53 @@ def golden_inpaint(ref, rec, out):
     np.savez_compressed(os.path.join(out, "inpaint.npz"), **d)
 
 
+def golden_fda(ref, rec, out):
+    """inpaint_nans_by_fda cases (fast=True and fast=False give the same raster; both are recorded
+    where they are cheap) with the (istop, itn) of the LSQR call inside."""
+    d = {}
+    cases = []
+    rng = np.random.default_rng(2718)
+
+    def add(tag, A, both=True):
+        rec.reset()
+        B = ref.inpaint_nans_by_fda(A)
+        calls = list(rec.lsqr_calls)
+        A2 = A.copy()
+        assert ref.inpaint_nans_by_fda(A2, inplace=True) is None
+        assert np.array_equal(A2, B, equal_nan=True)
+        if both:
+            B2 = ref.inpaint_nans_by_fda(A, fast=False)
+            d[tag + "_slow_equal"] = np.array(np.array_equal(B, B2, equal_nan=True))
+            d[tag + "_slow_maxdiff"] = np.array(float(np.nanmax(np.abs(B - B2))) if B.size else 0.0)
+        d[tag + "_in"] = A
+        d[tag + "_out"] = B
+        d[tag + "_lsqr"] = np.array(calls[0], dtype=np.int64)
+        cases.append(tag)
+        print("fda", tag, A.shape, int(np.isnan(A).sum()), calls[0],
+              d.get(tag + "_slow_maxdiff"), flush=True)
+
+    base = synth_dem(128, seed=11, dtype=np.float64)
+    A = base[:64, :72].copy(); A[rng.random(A.shape) >= 0.60] = np.nan; add("occ60", A)
+    A = base[:48, :40].copy(); A[rng.random(A.shape) >= 0.15] = np.nan; add("occ15", A)
+    A = base[:60, :50].copy(); A[20:38, 15:35] = np.nan; add("hole18", A)
+    A = base[:40, :50].copy()
+    A[0, :] = np.nan; A[:, 0] = np.nan; A[-1, -7:] = np.nan; A[-5:, -1] = np.nan; A[10:14, 10:30] = np.nan
+    add("borders", A)
+    A = base[:12, :12].copy(); A[0, 0] = np.nan; A[0, -1] = np.nan; A[-1, 0] = np.nan; A[5, 5] = np.nan; add("corners", A)
+    A = base[:9, :11].copy(); A[:] = np.nan; add("allnan", A)
+    A = base[:9, :11].copy(); add("nonan", A)
+    for shape in ((1, 30), (30, 1)):                       # a single row / column: the reference raises
+        try:
+            ref.inpaint_nans_by_fda(np.full(shape, np.nan))
+            raise AssertionError("expected ValueError")
+        except ValueError as e:
+            d["error_%dx%d" % shape] = np.array(str(e))
+    A = base[:2, :20].copy(); A[0, 3:9] = np.nan; A[1, 12] = np.nan; add("rows2", A)
+    A = base[:3, :3].copy(); A[1, 1] = np.nan; add("tiny3", A)
+    d["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(out, "fda.npz"), **d)
+
+
 def golden_create_dem(ref, rec, out):
     d = {}
     cases = []
@@ -522,10 +569,14 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "pssm":
         golden_pssm(ref, out)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "fda":
+        golden_fda(ref, Recorder(ref), out)
+        return
     rec = Recorder(ref)
     golden_samples(out)
     golden_progressive_filter(ref, rec, out)
     golden_inpaint(ref, rec, out)
+    golden_fda(ref, rec, out)
     golden_create_dem(ref, rec, out)
     golden_las(ref, out)
     golden_pssm(ref, out)
