@@ -2,9 +2,11 @@
 
 The raster's rows are split into ``world_size`` contiguous bands.  A grey opening by ``disk(r)``
 needs ``last`` on 2r rows either side of the band (r for the erosion the dilation reads, r more
-for that erosion's own footprint), so every window does ONE exchange of 2r rows with each
-neighbour (RCCL send/recv over the direct xGMI link; nearest-neighbour only, no collective),
-recomputes the erosion on the r halo rows redundantly and then dilates + flags its own rows.
+for that erosion's own footprint), so a window costs 2r rows of the neighbours' bands.
+Consecutive windows are grouped (``window_groups``): a group does ONE exchange of sum(2r) rows
+with each neighbour (RCCL send/recv over the direct xGMI link; nearest-neighbour only, no
+collective) and recomputes its shrinking margins redundantly, so windows 1..50 on 2048-row bands
+take 29 exchanges instead of 50.
 Image borders use scipy's reflect rule inside the kernels, exactly as on one GPU, so the result
 is bit-identical to the single-device path (neilpy.py:1659-1680 semantics).
 
@@ -19,7 +21,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["band_rows", "HipBandOps", "progressive_filter_sharded", "HipSpringsOps",
+__all__ = ["band_rows", "window_groups", "HipBandOps", "progressive_filter_sharded", "HipSpringsOps",
            "inpaint_nans_by_springs_sharded", "create_dem_band"]
 
 
@@ -94,15 +96,38 @@ def _exchange(dist, group, rank, world, send_up, recv_up, send_down, recv_down):
         dst.copy_(h)
 
 
+def window_groups(windows, min_band_rows, budget=None):
+    """Consecutive windows that share ONE halo exchange: a group needs sum(2r) rows of the
+    neighbours' bands up front and recomputes its margins redundantly while they shrink by 2r per
+    window.  Greedy: a group grows while its halo stays within ``budget`` rows (default: 1/16 of
+    the shortest band, at least 64; a single window always fits).  Fewer, larger messages: the
+    small radii, whose kernels are short, would otherwise pay one exchange latency each."""
+    if budget is None:
+        budget = max(64, min_band_rows // 16)
+    budget = min(budget, min_band_rows)
+    groups, cur, need = [], [], 0
+    for i, r in enumerate(windows):
+        if cur and need + 2 * r > budget:
+            groups.append(cur)
+            cur, need = [], 0
+        cur.append(i)
+        need += 2 * r
+    if cur:
+        groups.append(cur)
+    return groups
+
+
 def progressive_filter_sharded(Z_band, img_rows, windows, thresholds, *, rank=None, world_size=None, group=None,
-                               ops=None, return_when_dropped=False, state=None):
+                               ops=None, return_when_dropped=False, state=None, halo_budget=None):
     """progressive_filter on this rank's row band ``Z_band`` (rows ``band_rows(img_rows, W, rank)``).
 
     Returns the band's ``(mask, when_dropped | None)`` as uint8 tensors on ``Z_band``'s device.
     ``thresholds`` = ``slope_threshold * (windows * cellsize)`` in float64, as on one device.
     Every band must have at least ``2 * max(windows)`` rows (a halo never spans two ranks).
     ``state`` (a dict) keeps the extended buffers between calls so a benchmark loop does not
-    re-allocate.
+    re-allocate (and reports ``state["exchanges"]``).  ``halo_budget``: rows of halo a group of
+    consecutive windows may share in one exchange (see :func:`window_groups`; 0 = one exchange
+    per window).
     """
     import torch
     import torch.distributed as dist
@@ -128,7 +153,8 @@ def progressive_filter_sharded(Z_band, img_rows, windows, thresholds, *, rank=No
         raise ValueError("row bands of %d rows are shorter than the 2*%d halo rows a window needs; "
                          "use fewer ranks for this raster" % (min_band, rmax))
     dev, dt = Z_band.device, Z_band.dtype
-    H = 2 * rmax if world_size > 1 else 0
+    groups = window_groups(windows, min_band, halo_budget) if world_size > 1 else [[i] for i in range(len(windows))]
+    H = max([sum(2 * windows[i] for i in g) for g in groups], default=0) if world_size > 1 else 0
     e0, e1 = max(0, b0 - H), min(img_rows, b1 + H)          # rows the extended buffers can hold
     st = state if state is not None else {}
     key = (nloc, cols, H, str(dt), str(dev))
@@ -137,8 +163,8 @@ def progressive_filter_sharded(Z_band, img_rows, windows, thresholds, *, rank=No
         st["key"] = key
         st["ext"] = [torch.empty((e1 - e0, cols), dtype=dt, device=dev) for _ in range(2)]
         st["ero"] = torch.empty((e1 - e0, cols), dtype=dt, device=dev)
-        st["mask"] = torch.empty((nloc, cols), dtype=torch.uint8, device=dev)
-        st["when"] = torch.empty((nloc, cols), dtype=torch.uint8, device=dev)
+        st["mask"] = torch.empty((e1 - e0, cols), dtype=torch.uint8, device=dev)
+        st["when"] = torch.empty((e1 - e0, cols), dtype=torch.uint8, device=dev)
     ext, ero, mask = st["ext"], st["ero"], st["mask"]
     when = st["when"] if return_when_dropped else None
     mask.zero_()
@@ -147,29 +173,37 @@ def progressive_filter_sharded(Z_band, img_rows, windows, thresholds, *, rank=No
     off = b0 - e0                                            # band's first row inside an ext buffer
     cur = 0
     ext[cur][off:off + nloc].copy_(Z_band)
-    for i, r in enumerate(windows):
-        last = ext[cur]
-        if world_size > 1 and r > 0:
-            h = 2 * r
-            lo, hi = max(0, b0 - h), min(img_rows, b1 + h)
+    st["exchanges"] = 0
+    for grp in groups:
+        # rows of `last` the whole group needs beyond the band: every opening eats 2r of them
+        M = sum(2 * windows[i] for i in grp) if world_size > 1 else 0
+        if M > 0:
+            last = ext[cur]
+            lo, hi = max(0, b0 - M), min(img_rows, b1 + M)
             _exchange(dist, group, rank, world_size,
-                      last[off:off + h], last[lo - e0:off] if rank > 0 else None,
-                      last[off + nloc - h:off + nloc], last[off + nloc:hi - e0] if rank < world_size - 1 else None)
-        else:
-            lo, hi = b0, b1
+                      last[off:off + M], last[lo - e0:off] if rank > 0 else None,
+                      last[off + nloc - M:off + nloc], last[off + nloc:hi - e0] if rank < world_size - 1 else None)
+            st["exchanges"] += 1
+        for i in grp:
+            r = windows[i]
+            last = ext[cur]
             if world_size == 1:
-                lo, hi = 0, img_rows
-        # erosion on the band plus r rows either side (clipped at the image border)
-        q0, q1 = max(0, b0 - r), min(img_rows, b1 + r)
-        src = last[lo - e0:hi - e0]
-        dst = ero[q0 - e0:q1 - e0]
-        ops.erode(src, lo, dst, q0, q1 - q0, img_rows, r)
-        nxt = ext[1 - cur]
-        ops.dilate_flag(dst, q0, q1 - q0, last[off:off + nloc], nxt[off:off + nloc], mask, when, float(thresholds[i]),
-                        i, b0, nloc, img_rows, r)
-        if len(windows) > 1:
-            cur = 1 - cur
-    return mask, when
+                lo, hi, q0, q1, o0, o1 = 0, img_rows, 0, img_rows, 0, img_rows
+            else:
+                lo, hi = max(0, b0 - M), min(img_rows, b1 + M)          # rows of `last` that are valid now
+                q0, q1 = max(0, b0 - M + r), min(img_rows, b1 + M - r)  # erosion: r rows inside them
+                M -= 2 * r
+                o0, o1 = max(0, b0 - M), min(img_rows, b1 + M)          # opening: r more rows inside (the band at the end)
+            dst = ero[q0 - e0:q1 - e0]
+            ops.erode(last[lo - e0:hi - e0], lo, dst, q0, q1 - q0, img_rows, r)
+            nxt = ext[1 - cur]
+            # margin rows are flagged too (same values the neighbour computes for them); only the band's are returned
+            ops.dilate_flag(dst, q0, q1 - q0, last[o0 - e0:o1 - e0], nxt[o0 - e0:o1 - e0], mask[o0 - e0:o1 - e0],
+                            when[o0 - e0:o1 - e0] if when is not None else None, float(thresholds[i]), i, o0, o1 - o0,
+                            img_rows, r)
+            if len(windows) > 1:
+                cur = 1 - cur
+    return mask[off:off + nloc], (when[off:off + nloc] if when is not None else None)
 
 
 # ------------------------------------------------------------------------------------------

@@ -2,8 +2,8 @@
 
 The product compute (HIP) cannot run here, so the band operations are injected: an
 oracle-backed BandOps that applies scipy's erosion / dilation to the extended band (halo rows
-present) and crops.  What is under test is neilpy_amd.sharded: band partitioning, the 2r-row
-exchange per window, the reflect handling at the raster's true borders and the flag/mask logic.
+present) and crops.  What is under test is neilpy_amd.sharded: band partitioning, the grouped
+halo exchange (sum of 2r rows per group of windows), the reflect handling at the raster's true borders and the flag/mask logic.
 The sharded result must equal the single-process oracle bit for bit.
 """
 import os
@@ -51,7 +51,7 @@ class OracleBandOps:
             when.numpy()[new_obj] = widx
 
 
-def _worker(rank, world, port, shape, windows, dtype_name, out_dir):
+def _worker(rank, world, port, shape, windows, dtype_name, out_dir, budget=None):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -68,22 +68,25 @@ def _worker(rank, world, port, shape, windows, dtype_name, out_dir):
         state = {}
         for _ in range(2):                       # second call reuses the buffers
             mask, when = sharded.progressive_filter_sharded(band, shape[0], win, thr, rank=rank, world_size=world,
-                                                            ops=OracleBandOps(), return_when_dropped=True, state=state)
-        np.savez(os.path.join(out_dir, "r%d.npz" % rank), mask=mask.numpy(), when=when.numpy(), b0=b0, b1=b1)
+                                                            ops=OracleBandOps(), return_when_dropped=True, state=state,
+                                                            halo_budget=budget)
+        np.savez(os.path.join(out_dir, "r%d.npz" % rank), mask=mask.numpy(), when=when.numpy(), b0=b0, b1=b1,
+                 exchanges=state["exchanges"])
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,shape,windows,dtype", [
-    (2, (96, 70), [1, 2, 3, 5, 8], "f32"),
-    (2, (61, 40), [1, 4, 9, 12], "f64"),
-    (3, (150, 33), [2, 1, 7, 11], "f32"),
+@pytest.mark.parametrize("world,shape,windows,dtype,budget,exchanges", [
+    (2, (96, 70), [1, 2, 3, 5, 8], "f32", None, 1),          # one group: 38 halo rows <= the 48-row bands
+    (2, (96, 70), [1, 2, 3, 5, 8], "f32", 0, 5),             # one exchange per window
+    (2, (61, 40), [1, 4, 9, 12], "f64", None, 2),            # (1, 4, 9) | 12 on 30-row bands
+    (3, (150, 33), [2, 1, 7, 11], "f32", 20, 2),             # (2, 1, 7) | 11 with a 20-row budget
 ])
-def test_sharded_equals_single(tmp_path, world, shape, windows, dtype):
+def test_sharded_equals_single(tmp_path, world, shape, windows, dtype, budget, exchanges):
     from oracle import smrf_oracle as orc
     from neilpy_amd.synth import synth_dem
-    port = 29500 + (os.getpid() % 2000) + world
-    mp.spawn(_worker, args=(world, port, shape, windows, dtype, str(tmp_path)), nprocs=world, join=True)
+    port = 29500 + (os.getpid() % 2000) + world + (7 if budget == 0 else 0)
+    mp.spawn(_worker, args=(world, port, shape, windows, dtype, str(tmp_path), budget), nprocs=world, join=True)
     Z = synth_dem(shape[1], seed=31, dtype=np.float32 if dtype == "f32" else np.float64, rows=shape[0])
     want_m, want_w = orc.progressive_filter(Z, np.asarray(windows), 1, .15, return_when_dropped=True)
     got_m = np.zeros(shape, np.uint8)
@@ -92,6 +95,7 @@ def test_sharded_equals_single(tmp_path, world, shape, windows, dtype):
         d = np.load(os.path.join(str(tmp_path), "r%d.npz" % r))
         got_m[int(d["b0"]):int(d["b1"])] = d["mask"]
         got_w[int(d["b0"]):int(d["b1"])] = d["when"]
+        assert int(d["exchanges"]) == exchanges
     assert np.array_equal(got_m.astype(bool), want_m)
     assert np.array_equal(got_w, want_w)
 
@@ -102,6 +106,18 @@ def test_band_too_short_raises():
     with pytest.raises(ValueError, match="halo"):
         sharded.progressive_filter_sharded(band, 20, np.array([6]), np.array([.9]), rank=0, world_size=2,
                                            ops=OracleBandOps())
+
+
+def test_window_groups():
+    from neilpy_amd.sharded import window_groups
+    w = list(range(1, 51))
+    g = window_groups(w, 2048)                               # the 8-GPU headline bands: 128-row budget
+    assert [i for grp in g for i in grp] == list(range(50)) and len(g) == 28
+    assert all(len(grp) == 1 or sum(2 * w[i] for i in grp) <= 128 for grp in g)
+    assert len(window_groups(w, 2048, 0)) == 50
+    assert window_groups([0, 0, 3], 100) == [[0, 1, 2]]
+    assert window_groups([], 100) == []
+    assert window_groups([40, 1], 100) == [[0], [1]]         # budget 64 -> 80 rows alone, then 2
 
 
 def test_band_rows_partition():

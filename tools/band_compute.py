@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Compute-only time of ONE rank's band of the sharded progressive_filter (developer tool).
+
+The halo exchange is stubbed out (margins hold stale rows; results are not checked), so one GPU
+can show what each of N ranks would spend in kernels, with and without window grouping:
+
+    python tools/band_compute.py --size 16384 --windows 50 --world 8 --rank 3
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ap = argparse.ArgumentParser()
+ap.add_argument("--size", type=int, default=16384)
+ap.add_argument("--windows", type=int, default=50)
+ap.add_argument("--world", type=int, default=8)
+ap.add_argument("--rank", type=int, default=3)
+ap.add_argument("--reps", type=int, default=5)
+a = ap.parse_args()
+import torch  # noqa: E402
+import neilpy_amd  # noqa: E402
+from neilpy_amd import sharded  # noqa: E402
+
+n = a.size
+b0, b1 = sharded.band_rows(n, a.world, a.rank)
+Z = torch.from_numpy(neilpy_amd.synth_dem(n, seed=20240, row_range=(b0, b1))).cuda()
+win = np.arange(1, a.windows + 1)
+thr = .15 * (win * 1)
+calls = [0]
+
+
+def no_exchange(*args, **kw):
+    calls[0] += 1
+
+
+sharded._exchange = no_exchange
+for budget in (0, None, 256, 512):
+    state = {}
+    ts = []
+    for i in range(a.reps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sharded.progressive_filter_sharded(Z, n, win, thr, rank=a.rank, world_size=a.world, state=state, halo_budget=budget)
+        torch.cuda.synchronize()
+        if i:
+            ts.append(time.perf_counter() - t0)
+    print("world %d rank %d band %d rows, halo budget %s: %d exchanges, %.2f ms compute-only per call "
+          "(1/%d of the single-GPU step would be the ideal)" % (a.world, a.rank, b1 - b0, budget, state["exchanges"],
+                                                               1e3 * float(np.median(ts)), a.world), flush=True)
