@@ -6,8 +6,8 @@
 A "step" is one full progressive_filter call (all windows: erosion + dilation + flagging per
 window) over the synthetic DEM ``synth_dem(n, seed=20240)`` already resident in HBM.  With N > 1
 (launched by torch.distributed.run, one rank per GPU) the DEM's rows are split into N bands and
-every window exchanges 2r halo rows with the neighbouring ranks over RCCL: the problem size is
-fixed, so ``scaling`` is "strong".  Rank 0 prints ONE JSON line (see README / DESIGN.md).
+groups of consecutive windows exchange their halo rows with the neighbouring ranks over RCCL
+(neilpy_amd/sharded.py): the problem size is fixed, so ``scaling`` is "strong".  Rank 0 prints ONE JSON line (see README / DESIGN.md).
 
 ``roofline``: the ring-kernel launches (2 per window) dominate; ``achieved`` is their
 algorithmic bytes per launch (N*(5*4+2)/2 = 11 B/cell) divided by their average
@@ -152,8 +152,9 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "progressive_filter %dx%d %s, windows 1..%d, cellsize 1, slope_threshold 0.15, "
                                    "synth_dem(seed=20240)" % (n, n, "fp32" if elem == 4 else "fp64", a.windows),
-                       "sharding": "row bands x%d, 2r-row halo exchange per window (RCCL send/recv)" % world
-                       if world > 1 else "single device", "object_cells": n_obj},
+                       "sharding": "row bands x%d, one halo exchange per group of windows (%d per step, RCCL send/recv)"
+                                   % (world, state.get("exchanges", 0)) if world > 1 else "single device",
+                       "object_cells": n_obj},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                          "traffic": traffic, "kernel": "smrf::ring_kernel (all radii; %d launches per step)" % launches,
                          "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": avg_launch_s * 1e3},
