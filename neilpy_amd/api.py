@@ -370,6 +370,8 @@ def smrf(x, y, z, cellsize=1, windows=5, slope_threshold=.15, elevation_threshol
     progressive filters and the slope raster run on the GPU with the rasters resident in HBM
     between stages, and so do the bicubic spline solve / evaluation and the point test of the tail
     (:1768-1795); only 1-D knot vectors and banded LU factors are prepared on the host.
+    NumPy / pandas points in -> NumPy results, as the reference; CUDA tensors in -> CUDA tensors
+    out (``dtm`` float64, ``object_grid`` and ``object_vector`` bool), nothing crosses PCIe.
     """
     torch = _torch()
     if np.isscalar(windows):
@@ -421,11 +423,18 @@ def smrf(x, y, z, cellsize=1, windows=5, slope_threshold=.15, elevation_threshol
     isobj_d = torch.empty(npts, dtype=torch.uint8, device=Zpro_d.device)
     _lib.check(lib.smrf_classify_points_f64(_ptr(elev_d), _ptr(slope_d), _ptr(zd), npts, float(elevation_threshold),
                                             float(elevation_scaler), _ptr(isobj_d), _stream()))      # :1794-1795
+    # diagnostics stay on the device until somebody reads them (tests compare them with FITPACK's values)
+    last_stats["tail"] = _DeviceValues(elevation_values=elev_d, slope_values=slope_d)
+    if _is_tensor(x) and _is_tensor(y) and _is_tensor(z):
+        # CUDA tensors in -> CUDA tensors out: nothing of the result crosses PCIe
+        obj_t, pts_t = object_cells.bool(), isobj_d.bool()
+        if not return_extras:
+            return Zpro_d, t, obj_t, pts_t
+        ri, ci = torch.round(r_d).long(), torch.round(c_d).long()      # round-half-even, as np.round
+        extras = {'above_ground_height': zd - elev_d, 'drop_raster': drop, 'when_dropped': drop[ri, ci]}
+        return Zpro_d, t, obj_t, pts_t, extras
     Zpro = Zpro_d.cpu().numpy()
     is_object_point = isobj_d.cpu().numpy().astype(bool)
-    elevation_values = elev_d.cpu().numpy()
-    last_stats["tail"] = dict(elevation_values=elevation_values, slope_values=slope_d.cpu().numpy())
-    zh = z if not _is_tensor(z) else z.cpu().numpy()
     try:                                            # the reference returns a Series when z is one (:1795)
         import pandas as pd
         if isinstance(z, pd.Series):
@@ -435,11 +444,31 @@ def smrf(x, y, z, cellsize=1, windows=5, slope_threshold=.15, elevation_threshol
     obj_np = object_cells.cpu().numpy().astype(bool)
     if not return_extras:
         return Zpro, t, obj_np, is_object_point
+    zh = z if not _is_tensor(z) else z.cpu().numpy()
+    elevation_values = elev_d.cpu().numpy()
     drop_raster = drop.cpu().numpy()
     r, c = r_d.cpu().numpy(), c_d.cpu().numpy()
     extras = {'above_ground_height': zh - elevation_values, 'drop_raster': drop_raster,
               'when_dropped': drop_raster[np.round(r).astype(int), np.round(c).astype(int)]}
     return Zpro, t, obj_np, is_object_point, extras
+
+
+class _DeviceValues:
+    """Read-only mapping of named device vectors, copied to NumPy on first access."""
+
+    def __init__(self, **tensors):
+        self._t, self._np = tensors, {}
+
+    def __getitem__(self, key):
+        if key not in self._np:
+            self._np[key] = self._t[key].cpu().numpy()
+        return self._np[key]
+
+    def keys(self):
+        return self._t.keys()
+
+    def __contains__(self, key):
+        return key in self._t
 
 
 # ------------------------------------------------------------------------------------------

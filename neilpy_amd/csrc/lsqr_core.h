@@ -11,7 +11,10 @@
 
 namespace {
 
-constexpr int MAXB = 1024;   // partial sums per reduction
+#ifndef SMRF_LSQR_MAXB
+#define SMRF_LSQR_MAXB 2048
+#endif
+constexpr int MAXB = SMRF_LSQR_MAXB;   // most blocks per vector kernel = partial sums per reduction
 
 struct Sc {
   double alfa, beta, inv_alfa, inv_beta;

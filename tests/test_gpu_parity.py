@@ -215,6 +215,24 @@ def check_smrf(nz, gold, x, y, z, kw, full, stride):
     return pts
 
 
+def test_smrf_tensor_in_tensor_out(nz, gpu_device):
+    """CUDA tensors in -> CUDA tensors out, equal to the NumPy path (which the goldens pin)."""
+    import torch
+    x, y, z, g = load_sample("samp24")
+    want = nz.smrf(x, y, z, 1, 18, .15, .5, 1.25, return_extras=True)
+    xd, yd, zd = (torch.from_numpy(v).to(gpu_device) for v in (x, y, z))
+    got = nz.smrf(xd, yd, zd, 1, 18, .15, .5, 1.25, return_extras=True)
+    assert got[0].is_cuda and got[0].dtype == torch.float64
+    assert got[2].dtype == torch.bool and got[3].dtype == torch.bool and got[3].is_cuda
+    assert np.array_equal(got[0].cpu().numpy(), want[0])
+    assert tuple(got[1]) == tuple(want[1])
+    assert np.array_equal(got[2].cpu().numpy(), want[2])
+    assert np.array_equal(got[3].cpu().numpy(), want[3])
+    for key in ("above_ground_height", "drop_raster", "when_dropped"):
+        assert np.array_equal(got[4][key].cpu().numpy(), want[4][key]), key
+    assert len(nz.smrf(xd, yd, zd)) == 4
+
+
 @pytest.mark.parametrize("name", SAMPLES)
 def test_smrf_samples_golden(nz, name):
     x, y, z, g = load_sample(name)

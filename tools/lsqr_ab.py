@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""A/B the spring-inpaint LSQR between library builds in one process (developer tool).
+
+    python tools/lsqr_ab.py --size 8192 --occupancy 0.09 --libs neilpy_amd/_lib/variants/x.so
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ap = argparse.ArgumentParser()
+ap.add_argument("--size", type=int, default=8192)
+ap.add_argument("--occupancy", type=float, default=0.09)
+ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--libs", default="")
+a = ap.parse_args()
+import torch  # noqa: E402
+import neilpy_amd  # noqa: E402
+from neilpy_amd import _lib  # noqa: E402
+
+lib = _lib.load()
+n = a.size
+g = torch.Generator(device="cuda").manual_seed(7)
+Z = torch.from_numpy(neilpy_amd.synth_dem(n, seed=20240).astype(np.float64)).cuda()
+Z[torch.rand((n, n), device="cuda", generator=g) >= a.occupancy] = float("nan")
+fns = {"cur": (lib.smrf_springs_lsqr_f64, lib.smrf_springs_workspace_bytes)}
+for path in [v for v in a.libs.split(",") if v]:
+    o = C.CDLL(os.path.abspath(path))
+    f, w = o.smrf_springs_lsqr_f64, o.smrf_springs_workspace_bytes
+    f.restype, f.argtypes = fns["cur"][0].restype, fns["cur"][0].argtypes
+    w.restype, w.argtypes = fns["cur"][1].restype, fns["cur"][1].argtypes
+    fns[os.path.basename(path)] = (f, w)
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+res = {}
+for i in range(a.reps + 1):
+    for name, (f, w) in fns.items():
+        nbytes = w(n, n)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        A = Z.clone()
+        istop, itn, nunk = C.c_int(0), C.c_int64(0), C.c_int64(0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = f(C.c_void_p(A.data_ptr()), n, n, 1e-6, 1e-6, 1e8, -1, C.byref(istop), C.byref(itn), C.byref(nunk),
+               C.c_void_p(ws.data_ptr()), nbytes, st)
+        assert rc == 0
+        e1.record()
+        torch.cuda.synchronize()
+        if i:
+            res.setdefault(name, []).append(e0.elapsed_time(e1))
+        res[name + "_info"] = (istop.value, itn.value, nunk.value, float(A.sum().item()))
+        del ws, A
+for name in fns:
+    t = float(np.median(res[name]))
+    istop, itn, nunk, s = res[name + "_info"]
+    print("%-12s %.1f ms  istop %d itn %d  %.3f ms/iter  %.0f GB/s at 106 B/cell/iter  sum %.6f" %
+          (name, t, istop, itn, t / max(itn, 1), n * n * 106.0 * itn / t / 1e6, s), flush=True)

@@ -73,5 +73,5 @@ torch.cuda.synchronize()
 stages["smrf_total_ms"] = (time.perf_counter() - t_all) * 1e3
 stages["points"] = a.points
 stages["Mpoints_per_s"] = a.points / stages["smrf_total_ms"] / 1e3
-stages["object_points"] = int(np.asarray(out[3]).sum())
+stages["object_points"] = int(out[3].sum().item())          # CUDA tensors in -> CUDA tensors out
 print(json.dumps(stages))
