@@ -63,5 +63,6 @@ def test_smrf_from_las_file(tmp_path, gpu_device):
     a = neilpy_amd.smrf(xd, yd, zd, 1, 18, .15, .5, 1.25)
     hx, df = neilpy_amd.read_las(fn)
     b = neilpy_amd.smrf(df.x.values, df.y.values, df.z.values, 1, 18, .15, .5, 1.25)
-    assert np.array_equal(a[2], b[2]) and np.array_equal(np.asarray(a[3]), np.asarray(b[3]))
-    assert np.array_equal(a[0], b[0])
+    assert a[0].is_cuda and a[3].is_cuda               # device points in -> device results out
+    assert np.array_equal(a[2].cpu().numpy(), b[2]) and np.array_equal(a[3].cpu().numpy(), np.asarray(b[3]))
+    assert np.array_equal(a[0].cpu().numpy(), b[0])
