@@ -41,7 +41,8 @@ for rep in range(2):
     dtm, T, obj, pts = neilpy_amd.smrf(xd, yd, zd, cellsize=a.cellsize, windows=a.windows)
     torch.cuda.synchronize()
     out["smrf_ms_run%d" % rep] = round((time.perf_counter() - t0) * 1e3, 1)
-out.update(grid=list(dtm.shape), object_cells=int(obj.sum()), object_points=int(np.asarray(pts).sum()),
+out.update(grid=list(dtm.shape), object_cells=int(obj.sum().item()), object_points=int(pts.sum().item()),   # CUDA tensors
+          
            lsqr=[neilpy_amd.last_stats["inpaint1"], neilpy_amd.last_stats["inpaint2"]],
            Mpoints_per_s=round(a.points / out["smrf_ms_run1"] / 1e3, 2))
 print(json.dumps(out))
