@@ -185,6 +185,24 @@ def progressive_filter(Z, windows, cellsize=1, slope_threshold=.15, return_when_
 # ------------------------------------------------------------------------------------------
 # create_dem  (neilpy.py:1110-1166)
 # ------------------------------------------------------------------------------------------
+def _dem_edges(xd, yd, cellsize):
+    """Cell edges of create_dem's raster from the points' extent (neilpy.py:1117-1124)."""
+    torch = _torch()
+    lib = _lib.load()
+    npts = xd.numel()
+    if npts == 0:
+        raise ValueError("zero-size array to reduction operation minimum which has no identity")
+    ws = torch.empty(4 * 1024, dtype=torch.float64, device=xd.device)
+    ext = (C.c_double * 4)()
+    _lib.check(lib.smrf_points_extent_f64(_ptr(xd), _ptr(yd), npts, ext, _ptr(ws), ws.numel() * 8, _stream()))
+    xmin, xmax, ymin, ymax = (np.float64(v) for v in ext)
+    xedges = np.arange(cellsize * np.floor(xmin / cellsize) - .5 * cellsize,
+                       cellsize * np.ceil(xmax / cellsize) + 1.5 * cellsize, cellsize)
+    yedges = np.arange(cellsize * np.ceil(ymax / cellsize) + .5 * cellsize,
+                       cellsize * np.floor(ymin / cellsize) - 1.5 * cellsize, -cellsize)
+    return xedges, yedges
+
+
 def _create_dem_device(xd, yd, zd, cellsize, bin_type, edges):
     """Device core: returns (float64 grid CUDA tensor, uint8 empty mask CUDA tensor, transform)."""
     torch = _torch()
@@ -192,16 +210,7 @@ def _create_dem_device(xd, yd, zd, cellsize, bin_type, edges):
     npts = xd.numel()
     h_filter = None
     if edges is None:
-        if npts == 0:
-            raise ValueError("zero-size array to reduction operation minimum which has no identity")
-        ws = torch.empty(4 * 1024, dtype=torch.float64, device=xd.device)
-        ext = (C.c_double * 4)()
-        _lib.check(lib.smrf_points_extent_f64(_ptr(xd), _ptr(yd), npts, ext, _ptr(ws), ws.numel() * 8, _stream()))
-        xmin, xmax, ymin, ymax = (np.float64(v) for v in ext)
-        xedges = np.arange(cellsize * np.floor(xmin / cellsize) - .5 * cellsize,
-                           cellsize * np.ceil(xmax / cellsize) + 1.5 * cellsize, cellsize)
-        yedges = np.arange(cellsize * np.ceil(ymax / cellsize) + .5 * cellsize,
-                           cellsize * np.floor(ymin / cellsize) - 1.5 * cellsize, -cellsize)
+        xedges, yedges = _dem_edges(xd, yd, cellsize)
     else:
         xedges, yedges = edges[0], edges[1]
         h_filter = (C.c_double * 4)(float(xedges[0]), float(xedges[-1]), float(yedges[-1]), float(yedges[0]))
@@ -361,6 +370,43 @@ def inpaint_nans_by_fda(A, fast=True, inplace=False):
 # ------------------------------------------------------------------------------------------
 # smrf  (neilpy.py:1685-1808)
 # ------------------------------------------------------------------------------------------
+def _classify_points_device(Zpro_d, t, cellsize, xd, yd, zd, elevation_threshold, elevation_scaler):
+    """smrf's tail on the device (neilpy.py:1768-1795): slope raster, the two interpolating bicubic
+    splines evaluated at the points' fractional pixel coordinates, and the point test.
+    Returns ``(elevation, slope, is_object (uint8), row, col)`` as CUDA vectors over the points."""
+    torch = _torch()
+    lib = _lib.load()
+    rows, cols = Zpro_d.shape
+    if rows < 4 or cols < 4:
+        raise ValueError("the bicubic spline of the point classification needs at least 4 x 4 cells")
+    S_d = torch.empty_like(Zpro_d)
+    _lib.check(lib.smrf_gradient_slope_f64(_ptr(Zpro_d), _ptr(S_d), rows, cols, float(cellsize), _stream()))   # :1785-1786
+
+    # RectBivariateSpline(row_centers, col_centers, .).ev(r, c) for Zpro and S on the device (:1768-1790)
+    from . import spline as _spline
+    h_inv = (C.c_double * 6)(*[float(v) for v in tuple(~t)[:6]])
+    c_d, r_d = torch.empty_like(xd), torch.empty_like(xd)
+    _lib.check(lib.smrf_affine_apply_f64(_ptr(xd), _ptr(yd), xd.numel(), h_inv, _ptr(c_d), _ptr(r_d), _stream()))  # :1772
+    tx, lur = _spline.axis_factors(rows)
+    ty, luc = _spline.axis_factors(cols)
+    tx_d, ty_d = torch.from_numpy(tx).to(Zpro_d.device), torch.from_numpy(ty).to(Zpro_d.device)
+    lur_d, luc_d = torch.from_numpy(lur).to(Zpro_d.device), torch.from_numpy(luc).to(Zpro_d.device)
+    npts = xd.numel()
+    vals = []
+    for plane in (Zpro_d, S_d):
+        coef = plane.clone()
+        _lib.check(lib.smrf_spline_solve_f64(_ptr(coef), rows, cols, _ptr(lur_d), _ptr(luc_d), _stream()))
+        out = torch.empty(npts, dtype=torch.float64, device=Zpro_d.device)
+        _lib.check(lib.smrf_spline_eval_f64(_ptr(coef), rows, cols, _ptr(tx_d), _ptr(ty_d), _ptr(r_d), _ptr(c_d), npts,
+                                            _ptr(out), _stream()))
+        vals.append(out)
+    elev_d, slope_d = vals
+    isobj_d = torch.empty(npts, dtype=torch.uint8, device=Zpro_d.device)
+    _lib.check(lib.smrf_classify_points_f64(_ptr(elev_d), _ptr(slope_d), _ptr(zd), npts, float(elevation_threshold),
+                                            float(elevation_scaler), _ptr(isobj_d), _stream()))      # :1794-1795
+    return elev_d, slope_d, isobj_d, r_d, c_d
+
+
 def smrf(x, y, z, cellsize=1, windows=5, slope_threshold=.15, elevation_threshold=.5,
          elevation_scaler=1.25, low_filter_slope=5, low_outlier_fill=False,
          return_extras=False):
@@ -395,34 +441,8 @@ def smrf(x, y, z, cellsize=1, windows=5, slope_threshold=.15, elevation_threshol
                                        Zmin.numel(), _stream()))                    # :1762-1763
     _springs_device(Zmin, "inpaint2")                                               # :1764
     Zpro_d = Zmin
-    rows, cols = Zpro_d.shape
-    if rows < 4 or cols < 4:
-        raise ValueError("the bicubic spline of the point classification needs at least 4 x 4 cells")
-    S_d = torch.empty_like(Zpro_d)
-    _lib.check(lib.smrf_gradient_slope_f64(_ptr(Zpro_d), _ptr(S_d), rows, cols, float(cellsize), _stream()))   # :1785-1786
-
-    # RectBivariateSpline(row_centers, col_centers, .).ev(r, c) for Zpro and S on the device (:1768-1790)
-    from . import spline as _spline
-    h_inv = (C.c_double * 6)(*[float(v) for v in tuple(~t)[:6]])
-    c_d, r_d = torch.empty_like(xd), torch.empty_like(xd)
-    _lib.check(lib.smrf_affine_apply_f64(_ptr(xd), _ptr(yd), xd.numel(), h_inv, _ptr(c_d), _ptr(r_d), _stream()))  # :1772
-    tx, lur = _spline.axis_factors(rows)
-    ty, luc = _spline.axis_factors(cols)
-    tx_d, ty_d = torch.from_numpy(tx).to(Zpro_d.device), torch.from_numpy(ty).to(Zpro_d.device)
-    lur_d, luc_d = torch.from_numpy(lur).to(Zpro_d.device), torch.from_numpy(luc).to(Zpro_d.device)
-    npts = xd.numel()
-    vals = []
-    for plane in (Zpro_d, S_d):
-        coef = plane.clone()
-        _lib.check(lib.smrf_spline_solve_f64(_ptr(coef), rows, cols, _ptr(lur_d), _ptr(luc_d), _stream()))
-        out = torch.empty(npts, dtype=torch.float64, device=Zpro_d.device)
-        _lib.check(lib.smrf_spline_eval_f64(_ptr(coef), rows, cols, _ptr(tx_d), _ptr(ty_d), _ptr(r_d), _ptr(c_d), npts,
-                                            _ptr(out), _stream()))
-        vals.append(out)
-    elev_d, slope_d = vals
-    isobj_d = torch.empty(npts, dtype=torch.uint8, device=Zpro_d.device)
-    _lib.check(lib.smrf_classify_points_f64(_ptr(elev_d), _ptr(slope_d), _ptr(zd), npts, float(elevation_threshold),
-                                            float(elevation_scaler), _ptr(isobj_d), _stream()))      # :1794-1795
+    elev_d, slope_d, isobj_d, r_d, c_d = _classify_points_device(Zpro_d, t, cellsize, xd, yd, zd, elevation_threshold,
+                                                                 elevation_scaler)
     # diagnostics stay on the device until somebody reads them (tests compare them with FITPACK's values)
     last_stats["tail"] = _DeviceValues(elevation_values=elev_d, slope_values=slope_d)
     if _is_tensor(x) and _is_tensor(y) and _is_tensor(z):

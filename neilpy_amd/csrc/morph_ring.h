@@ -5,19 +5,25 @@
 //     E[y, x] = min over dy in [-R, R] of  min over |dx| <= w(dy) of  Z[fold(y+dy), fold(x+dx)],
 //     w(dy) = isqrt(R*R - dy*dy)
 //
-// How: a workgroup owns a strip of TW columns (one column per lane) and marches down the rows of
-// its segment.  For every input row it stages TW+2R cells into LDS with coalesced loads, builds
-// the row's power-of-two window minima (a per-row sparse table, log2(2R+1) levels) and each lane
-// looks up the K distinct window minima R_w[x] of the disk (K ~ 0.59 R + 1, two LDS reads each).
-// The 2R+1 output rows that the input row contributes to are 2R+1 accumulators held in
-// REGISTERS: slot s belongs to output row y_in - R + s.  Moving to the next input row shifts
-// every slot down by one, which costs nothing because the update
-//     acc[s] = min(acc[s+1], R_w(dy = R - s))
-// writes a different register than it reads; with R a template parameter every slot index and
-// every window width is a compile-time constant, so the whole update is 2R straight-line
-// v_min_f32 (v_max for dilation) on fixed registers.  acc[0] is complete after the update and is
-// written out (coalesced).  No MFMA: there is no contraction in this computation; the kernel is
-// bound by LDS reads + VALU min/max, HBM traffic is ~2 plane passes.
+// How (details and measurements: DESIGN.md 4.1): a workgroup owns a strip of TW = 256 columns (one
+// column per lane) and marches down the rows of its segment, NP row PAIRS per batch.
+//   - The two rows of a pair are interleaved per cell in LDS ({rowA[x], rowB[x]}), so one
+//     ds_read_b64 / ds_write_b64 serves both rows.  A batch is prefetched into registers one batch
+//     ahead with coalesced global loads; level 0 of the table is double buffered.
+//   - Per row a sparse table of power-of-two window minima is built in two stages of independent
+//     reads (base level from the staged row, higher levels from the base level), 3 barriers per batch.
+//   - Each lane looks up the K distinct window minima of disk(R) (K ~ 0.59 R + 1; two reads of one
+//     level each), in software-pipelined groups of G widths.  All table reads are inline asm
+//     ds_read_b64 with counted s_waitcnt: hipcc would fuse them into half-rate ds_read2_b64.
+//   - The 2R output rows a pair contributes to are 2R accumulators in REGISTERS: slot s belongs to
+//     output row y_in - R + s.  After a pair every slot moves down by two for free, because
+//         acc[s] = min3(acc[s+2], RA[k(R-s-2)], RB[k(R-s-1)])
+//     writes a different register than it reads; with R a template parameter every slot index and
+//     window width is a compile-time constant, so the update is straight-line v_min3_f32 (v_max3
+//     for dilation) on fixed registers.  Completed rows are stored one batch late (coalesced).
+//   - The dilation instance fuses progressive_filter's flag step (neilpy.py:1671-1674).
+// No MFMA: there is no contraction in this computation; the kernel is bound by VALU min/max issue
+// and LDS reads, HBM traffic is ~2 plane passes per launch.
 #pragma once
 #include <algorithm>
 #include <utility>
@@ -91,7 +97,6 @@ struct DiskTables {
 template <int R>
 struct DiskShape {
   static constexpr DiskTables<R> tab{};
-  static constexpr int halfw(int dy) { return tab.halfw[dy]; }
   static constexpr int kidx(int dy) { return tab.kidx[dy]; }   // dy in [0, R]
   static constexpr int K = tab.K;                             // number of distinct half-widths
   static constexpr int wk(int k) { return tab.wk[k]; }        // k-th distinct half-width
@@ -215,7 +220,6 @@ struct RingCfg {
   static constexpr int WG_LDS = (int)(160 * 1024 / LDS_BYTES) < 1 ? 1 : (int)(160 * 1024 / LDS_BYTES);
   static constexpr int OCC_LDS = WG_LDS * WAVES / 4 < 1 ? 1 : WG_LDS * WAVES / 4;
   static constexpr int OCC = OCC_REG < OCC_LDS ? OCC_REG : OCC_LDS;   // waves per SIMD the kernel is built for
-  static constexpr int WG_PER_CU = OCC * 4 / WAVES < 1 ? 1 : OCC * 4 / WAVES;
   // ring slot s (0 .. 2R-3) after a pair takes min3(acc[s+2], RA[kA(s)], RB[kB(s)])
   static constexpr int kA(int s) { int d = R - s - 2; return S::kidx(d < 0 ? -d : d); }
   static constexpr int kB(int s) { int d = R - s - 1; return S::kidx(d < 0 ? -d : d); }

@@ -22,7 +22,7 @@ import numpy as np
 from . import _lib
 
 __all__ = ["band_rows", "window_groups", "HipBandOps", "progressive_filter_sharded", "HipSpringsOps",
-           "inpaint_nans_by_springs_sharded", "create_dem_band"]
+           "inpaint_nans_by_springs_sharded", "create_dem_band", "smrf_sharded"]
 
 
 def band_rows(img_rows, world_size, rank):
@@ -375,3 +375,95 @@ def create_dem_band(xd, yd, zd, inv_affine, grid_shape, *, rank, world_size, bin
                                      p(n_out), st))
     _lib.check(lib.smrf_grid_finalize_f64(p(keys), p(grid), p(empty), keys.numel(), is_max, st))
     return grid, empty, int(n_out.item())
+
+
+# ------------------------------------------------------------------------------------------
+# the whole smrf() over row bands
+# ------------------------------------------------------------------------------------------
+def _all_gather_rows(dist, group, part, sizes):
+    """Concatenate every rank's leading-dimension block (``sizes[k]`` rows on rank k) on every rank.
+    Blocks are padded to the largest one (all_gather wants equal shapes); gloo stages CUDA tensors
+    through the host."""
+    import torch
+    world = len(sizes)
+    if world == 1:
+        return part
+    pad = max(sizes)
+    buf = torch.zeros((pad,) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)
+    buf[:part.shape[0]].copy_(part)
+    staged = dist.get_backend(group) == "gloo" and part.is_cuda
+    src = buf.cpu() if staged else buf
+    outs = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(outs, src, group=group)
+    full = torch.cat([o[:n] for o, n in zip(outs, sizes)], dim=0)
+    return full.to(part.device) if staged else full
+
+
+def smrf_sharded(x, y, z, cellsize=1, windows=5, slope_threshold=.15, elevation_threshold=.5, elevation_scaler=1.25,
+                 low_filter_slope=5, low_outlier_fill=False, *, rank=None, world_size=None, group=None):
+    """neilpy.smrf (neilpy/neilpy.py:1685-1808) with the raster split into row bands, one rank per GPU.
+
+    Every rank passes the FULL point set (replicated, or read by every rank from the same file).
+    Gridding, both spring inpaints and both progressive filters run on this rank's band
+    (create_dem_band, inpaint_nans_by_springs_sharded, progressive_filter_sharded).  The tail's
+    bicubic spline is global along both axes, so the DTM bands are all-gathered and every rank
+    solves the spline on the whole raster ("replicas only") but evaluates and tests only
+    its own 1/N of the points; the point flags are all-gathered.
+
+    Returns ``(dtm_band, transform, object_cells_band, is_object_point, (b0, b1))``: the rank's rows
+    ``b0:b1`` of the DTM (float64 CUDA) and of the object raster (bool CUDA), and the flags of ALL
+    points (bool CUDA, same on every rank).
+    """
+    import torch
+    import torch.distributed as dist
+    from . import api
+    if world_size is None:
+        world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if np.isscalar(windows):
+        windows = np.arange(windows) + 1
+    windows = np.asarray(windows)
+    lib = _lib.load()
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)    # noqa: E731
+    st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)              # noqa: E731
+    xd, yd, zd = api._points_to_device(x, y, z)
+    xedges, yedges = api._dem_edges(xd, yd, cellsize)                              # :1117-1124, same on every rank
+    nx, ny = len(xedges) - 1, len(yedges) - 1
+    from .affine import from_origin
+    t = from_origin(xedges[0], yedges[0], cellsize, cellsize)
+    b0, b1 = band_rows(ny, world_size, rank)
+    band, empty, n_out = create_dem_band(xd, yd, zd, tuple(~t)[:6], (ny, nx), rank=rank, world_size=world_size,
+                                         bin_type='min')                           # :1741
+    if n_out > 0:
+        raise ValueError("invalid entry in coordinates array")
+    stats = {"inpaint1": inpaint_nans_by_springs_sharded(band, ny, rank=rank, world_size=world_size, group=group)}
+    neg = torch.empty_like(band)
+    _lib.check(lib.smrf_negate_f64(p(band), p(neg), band.numel(), st()))
+    low, _ = progressive_filter_sharded(neg, ny, np.array([1]), low_filter_slope * (np.array([1]) * cellsize),
+                                        rank=rank, world_size=world_size, group=group)                 # :1744
+    low = low.clone()
+    del neg
+    if low_outlier_fill:                                                           # :1747-1749
+        _lib.check(lib.smrf_mask_apply_f64(p(band), p(low), None, None, None, band.numel(), st()))
+        stats["inpaint1b"] = inpaint_nans_by_springs_sharded(band, ny, rank=rank, world_size=world_size, group=group)
+    obj, _ = progressive_filter_sharded(band, ny, windows, slope_threshold * (windows * cellsize), rank=rank,
+                                        world_size=world_size, group=group)        # :1752-1755
+    obj = obj.contiguous()
+    object_cells = torch.empty_like(obj)
+    _lib.check(lib.smrf_mask_apply_f64(p(band), p(empty), p(low), p(obj), p(object_cells), band.numel(), st()))   # :1762-1763
+    stats["inpaint2"] = inpaint_nans_by_springs_sharded(band, ny, rank=rank, world_size=world_size, group=group)  # :1764
+    # tail: the spline needs the whole DTM; the points are split evenly
+    sizes = [band_rows(ny, world_size, k)[1] - band_rows(ny, world_size, k)[0] for k in range(world_size)]
+    Zpro = _all_gather_rows(dist, group, band, sizes)
+    npts = xd.numel()
+    psz = [band_rows(npts, world_size, k)[1] - band_rows(npts, world_size, k)[0] for k in range(world_size)]
+    p0, p1 = band_rows(npts, world_size, rank)
+    if p1 > p0:
+        part = api._classify_points_device(Zpro, t, cellsize, xd[p0:p1].contiguous(), yd[p0:p1].contiguous(),
+                                           zd[p0:p1].contiguous(), elevation_threshold, elevation_scaler)[2]
+    else:
+        part = torch.empty(0, dtype=torch.uint8, device=xd.device)
+    flags = _all_gather_rows(dist, group, part, psz)
+    api.last_stats["sharded"] = stats
+    return band, t, object_cells.bool(), flags.bool(), (b0, b1)

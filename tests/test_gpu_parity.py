@@ -387,3 +387,26 @@ def test_sharded_stages_rehearsal(nz, world):
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert j["create_dem_band_ok"] and j["lsqr_itn_ok"] and j["progressive_filter_ok"], j
     assert j["inpaint_max_abs_err"] < 1e-7, j
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_smrf_sharded_rehearsal(nz, world):
+    """the whole smrf() over row bands (neilpy_amd.sharded.smrf_sharded) on 1 and 3 ranks sharing this
+    GPU (gloo-staged halos and gathers) against samp11's goldens: object raster and point flags bit-exact,
+    both LSQR solves stop at the reference's iteration, DTM within 1e-7"""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = os.path.join(ROOT, "tools", "smrf_sharded_rehearsal.py")
+    if world == 1:
+        cmd = [sys.executable, script, "--sample", "samp11"]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(29650 + world), script, "--sample", "samp11",
+               "--backend", "gloo", "--share-gpu"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["object_cells_ok"] and j["is_object_point_ok"] and j["transform_ok"] and j["lsqr_itn_ok"], j
+    assert j["dtm_err"] < 1e-7 and j["object_points"] == 16384, j
