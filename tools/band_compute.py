@@ -40,14 +40,17 @@ def no_exchange(*args, **kw):
 sharded._exchange = no_exchange
 for budget in (0, None, 256, 512):
     state = {}
-    ts = []
+    ts, tq = [], []
     for i in range(a.reps + 1):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         sharded.progressive_filter_sharded(Z, n, win, thr, rank=a.rank, world_size=a.world, state=state, halo_budget=budget)
+        t1 = time.perf_counter()                           # all launches enqueued: the host's share
         torch.cuda.synchronize()
         if i:
             ts.append(time.perf_counter() - t0)
+            tq.append(t1 - t0)
     print("world %d rank %d band %d rows, halo budget %s: %d exchanges, %.2f ms compute-only per call "
-          "(1/%d of the single-GPU step would be the ideal)" % (a.world, a.rank, b1 - b0, budget, state["exchanges"],
-                                                               1e3 * float(np.median(ts)), a.world), flush=True)
+          "(host enqueue %.2f ms; 1/%d of the single-GPU step would be the ideal)"
+          % (a.world, a.rank, b1 - b0, budget, state["exchanges"], 1e3 * float(np.median(ts)), 1e3 * float(np.median(tq)),
+             a.world), flush=True)

@@ -24,7 +24,6 @@ def main():
     ap.add_argument("--libs", default="", help="comma list of extra libsmrf_hip builds to interleave (A/B in one process)")
     a = ap.parse_args()
     import torch
-    import neilpy_amd
     from neilpy_amd import _lib
     lib = _lib.load()
     n = a.n

@@ -4,7 +4,6 @@
     python tools/smrf_stages.py --points 20000000 --extent 8192 --windows 18
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
