@@ -617,7 +617,12 @@ int ring_launch(const DiskArgs<T>& a_in, hipStream_t stream) {
   constexpr int NP = SMRF_RING_NP(T, R);
   using C = RingCfg<T, R, TW, NP>;
   auto kern = ring_kernel<T, R, DIL, TW, NP>;
-  static int resident = 0;                               // workgroups one CU really holds (registers + LDS)
+  // workgroups one CU really holds (registers + LDS), per device: the attribute below is per device too
+  static int resident_of[64] = {0};
+  int dev = 0;
+  SMRF_HIP_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return smrf_fail(SMRF_E_UNSUPPORTED, "device index %d out of range", dev);
+  int& resident = resident_of[dev];
   if (resident == 0) {
     if (C::LDS_BYTES > 48 * 1024)
       SMRF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
