@@ -136,6 +136,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         dt, dev_ms, n_obj = float(tmax[0]), float(tmax[1]), int(t[2])
 
+    # what a plain device copy of one plane reaches on this GPU (read + write), for context beside the 8 TB/s spec
+    copy_gbps = None
+    if rank == 0:
+        tmp = torch.empty_like(Z)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tmp.copy_(Z)
+        c0.record()
+        for _ in range(5):
+            tmp.copy_(Z)
+        c1.record()
+        torch.cuda.synchronize()
+        copy_gbps = 5 * 2 * Z.numel() * Z.element_size() / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        del tmp
     if rank == 0:
         cells = n * n
         elem = 4 if a.dtype == "f32" else 8
@@ -166,7 +179,8 @@ def main():
                        "object_cells": n_obj},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                          "traffic": traffic, "kernel": "smrf::ring_kernel (all radii; %d launches per step)" % launches,
-                         "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": avg_launch_s * 1e3},
+                         "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": avg_launch_s * 1e3,
+                         "device_copy_gbps": copy_gbps, "frac_of_device_copy": achieved / copy_gbps},
         }
         if crop is not None:
             out["cpu_baseline"] = cpu_baseline(crop, windows, cellsize, slope)
