@@ -81,52 +81,38 @@ def test_cfg4_progressive_filter_monotone_and_pinned(nz, Z4):
 
 
 def test_cfg4_sharded_driver_equals_single_device(nz, Z4):
-    """the row-band driver (8 bands, grouped halo exchange replaced by slicing the true neighbour rows)"""
+    """neilpy_amd.sharded's row-band driver on the 8 bands of cfg4, one rank after the other on this GPU.
+    The neighbour exchange is replaced by copying the same rows out of the surface that enters each group
+    of windows (computed on the whole raster), which is what the neighbours would send."""
     import torch
     from neilpy_amd import sharded
-    win = np.arange(1, 13)                                     # 12 windows: groups (1..10), (11, 12) on 2048-row bands
+    win = np.arange(1, 13)                                     # groups (1..10), (11, 12) on 2048-row bands
     thr = .15 * (win * 1)
     want = nz.progressive_filter(Z4, win, 1, .15)
     world = 8
-    # emulate the exchange: every rank's margins are filled from the neighbours' current surfaces, which needs all
-    # ranks in lock step; run the ranks round-robin group by group through the driver's own building blocks
-    bands = [sharded.band_rows(N4, world, k) for k in range(world)]
-    state = [dict() for _ in range(world)]
-    surfaces = {}
-
-    def exchange(dist, group, rank, world_size, send_up, recv_up, send_down, recv_down):
-        # called once per group by rank `rank`: take the margins from the neighbours' surfaces of the same group
-        M = send_up.shape[0]
-        b0, b1 = bands[rank]
-        cur = surfaces[exchange.group_index]
-        if recv_up is not None:
-            recv_up.copy_(cur[b0 - recv_up.shape[0]:b0])
-        if recv_down is not None:
-            recv_down.copy_(cur[b1:b1 + recv_down.shape[0]])
-        assert M <= b1 - b0
-
-    # the surface entering group g is the opening after the previous group's last window: compute it on one device
-    groups = sharded.window_groups([int(w) for w in win], 2048)
-    last = Z4
-    for g, grp in enumerate(groups):
-        surfaces[g] = last
+    groups = sharded.window_groups([int(w) for w in win], N4 // world)
+    assert [len(g) for g in groups] == [10, 2]
+    entering, last = [], Z4                                    # the surface each group starts from
+    for grp in groups:
+        entering.append(last)
         for i in grp:
             last = nz.opening(last, radius=int(win[i]))
     real = sharded._exchange
-    sharded._exchange = exchange
     try:
         for k in range(world):
-            b0, b1 = bands[k]
+            b0, b1 = sharded.band_rows(N4, world, k)
             calls = []
 
-            def counting(*a, **kw):
-                exchange.group_index = len(calls)
-                calls.append(1)
-                return exchange(*a, **kw)
-            sharded._exchange = counting
-            mask, _ = sharded.progressive_filter_sharded(Z4[b0:b1], N4, win, thr, rank=k, world_size=world,
-                                                          state=state[k])
-            assert len(calls) == len(groups)
+            def fake_exchange(dist, group, rank, world_size, send_up, recv_up, send_down, recv_down):
+                src = entering[len(calls)]
+                calls.append(send_up.shape[0])
+                if recv_up is not None:
+                    recv_up.copy_(src[b0 - recv_up.shape[0]:b0])
+                if recv_down is not None:
+                    recv_down.copy_(src[b1:b1 + recv_down.shape[0]])
+            sharded._exchange = fake_exchange
+            mask, _ = sharded.progressive_filter_sharded(Z4[b0:b1], N4, win, thr, rank=k, world_size=world)
+            assert calls == [sum(2 * int(win[i]) for i in g) for g in groups]      # one exchange per group, sum(2r) rows
             assert torch.equal(mask.bool(), want[b0:b1]), k
     finally:
         sharded._exchange = real
