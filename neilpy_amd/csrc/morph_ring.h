@@ -48,6 +48,9 @@
 #ifndef SMRF_RING_NP_MAX
 #define SMRF_RING_NP_MAX 2
 #endif
+#ifndef SMRF_RING_XCD_REMAP
+#define SMRF_RING_XCD_REMAP 1   // XCD-aware tile placement (see ring_kernel)
+#endif
 #ifndef SMRF_RING_OCC_DROP
 #define SMRF_RING_OCC_DROP 0   // tuning builds: run every radius one occupancy step below the estimate
 #endif
@@ -301,9 +304,22 @@ void ring_kernel(const DiskArgs<T> a) {
   T2* const L = reinterpret_cast<T2*>(smrf_lds);         // [NP][NLEV][WP] of {row A, row B}
 
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * TW;
+  // Workgroups are dealt round-robin over the 8 XCDs in dispatch order (x fastest), each XCD with
+  // its own L2.  Remap the tile so that an XCD owns a contiguous range of strips (all their
+  // segments): neighbouring strips share 2R halo columns, which then hit the same L2.  Placement
+  // only, any mapping is correct (MI355X_MICROARCH: workgroup dispatch, XCD placement).
+  int bx = blockIdx.x, by = blockIdx.y;
+#if SMRF_RING_XCD_REMAP
+  if ((gridDim.x & 7) == 0) {
+    const int id = blockIdx.y * gridDim.x + blockIdx.x, per = gridDim.x >> 3;
+    const int xcd = id & 7, slot = id >> 3;
+    bx = xcd * per + slot % per;
+    by = slot / per;
+  }
+#endif
+  const int x0 = bx * TW;
   const int x = x0 + tid;
-  const int ys = a.out_row0 + blockIdx.y * a.seg;        // global output rows [ys, ye)
+  const int ys = a.out_row0 + by * a.seg;                // global output rows [ys, ye)
   const int ye = min(a.out_row0 + a.out_rows, ys + a.seg);
   constexpr int NPOS = C::NPOS, W = C::W;
   // lane-owned staged cells: positions tid + i*TW of the TW+2R wide row; only the last can be absent
