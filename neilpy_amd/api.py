@@ -451,6 +451,12 @@ def smrf(x, y, z, cellsize=1, windows=5, slope_threshold=.15, elevation_threshol
         if not return_extras:
             return Zpro_d, t, obj_t, pts_t
         ri, ci = torch.round(r_d).long(), torch.round(c_d).long()      # round-half-even, as np.round
+        if ri.numel() and (int(ri.min()) < -drop.shape[0] or int(ri.max()) >= drop.shape[0] or
+                           int(ci.min()) < -drop.shape[1] or int(ci.max()) >= drop.shape[1]):
+            # the reference indexes drop_raster with the rounded pixel coordinates (:1780) and NumPy raises for a
+            # point that rounds onto the raster's far edge; a device gather must not be handed such an index
+            raise IndexError("index %d is out of bounds for the drop raster of shape %s"
+                             % (max(int(ri.max()), int(ci.max())), tuple(drop.shape)))
         extras = {'above_ground_height': zd - elev_d, 'drop_raster': drop, 'when_dropped': drop[ri, ci]}
         return Zpro_d, t, obj_t, pts_t, extras
     Zpro = Zpro_d.cpu().numpy()

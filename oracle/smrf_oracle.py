@@ -393,7 +393,8 @@ def smrf(x, y, z, cellsize=1, windows=5, slope_threshold=.15, elevation_threshol
     c, r = ~t * (x, y)
     f1 = interpolate.RectBivariateSpline(row_centers, col_centers, Zpro)
     elevation_values = f1.ev(r, c)
-    when_dropped = drop_raster[np.round(r).astype(int), np.round(c).astype(int)]
+    if return_extras:                                                   # :1777-1780 (an IndexError there is the reference's too)
+        when_dropped = drop_raster[np.round(r).astype(int), np.round(c).astype(int)]
     gy, gx = np.gradient(Zpro, cellsize)
     S = np.sqrt(gy ** 2 + gx ** 2)
     f2 = interpolate.RectBivariateSpline(row_centers, col_centers, S)
