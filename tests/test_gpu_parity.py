@@ -410,3 +410,24 @@ def test_smrf_sharded_rehearsal(nz, world):
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert j["object_cells_ok"] and j["is_object_point_ok"] and j["transform_ok"] and j["lsqr_itn_ok"], j
     assert j["dtm_err"] < 1e-7 and j["object_points"] == 16384, j
+
+
+def test_integration_md_stub_runs(nz, orc):
+    """The ctypes binding shown in INTEGRATION.md section 2 is executed as written (only the library path is
+    made absolute) and must equal the oracle."""
+    import re
+    from conftest import ROOT
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = [b for b in blocks if "ctypes.CDLL" in b]
+    assert len(stub) == 1
+    src = stub[0].replace('"libsmrf_hip.so"', repr(nz.LIB_PATH))
+    ns = {}
+    exec(compile(src, "INTEGRATION.md", "exec"), ns)
+    rng = np.random.default_rng(3)
+    Z = rand_dem(rng, (120, 150), np.float32)
+    win = np.arange(1, 9)
+    m, w = ns["progressive_filter"](Z, win, 1, .15, return_when_dropped=True)
+    m2, w2 = orc.progressive_filter(Z, win, 1, .15, return_when_dropped=True)
+    assert m.dtype == bool and np.array_equal(m, m2) and np.array_equal(w, w2)
+    assert np.array_equal(ns["progressive_filter"](Z.astype(np.float64), win), m2)
