@@ -86,12 +86,12 @@ def test_cfg4_sharded_driver_equals_single_device(nz, Z4):
     of windows (computed on the whole raster), which is what the neighbours would send."""
     import torch
     from neilpy_amd import sharded
-    win = np.arange(1, 13)                                     # groups (1..10), (11, 12) on 2048-row bands
+    win = np.arange(1, 19)                                     # groups (1..15), (16..18) on 2048-row bands
     thr = .15 * (win * 1)
     want = nz.progressive_filter(Z4, win, 1, .15)
     world = 8
     groups = sharded.window_groups([int(w) for w in win], N4 // world)
-    assert [len(g) for g in groups] == [10, 2]
+    assert [len(g) for g in groups] == [15, 3]
     entering, last = [], Z4                                    # the surface each group starts from
     for grp in groups:
         entering.append(last)

@@ -111,13 +111,15 @@ def test_band_too_short_raises():
 def test_window_groups():
     from neilpy_amd.sharded import window_groups
     w = list(range(1, 51))
-    g = window_groups(w, 2048)                               # the 8-GPU headline bands: 128-row budget
-    assert [i for grp in g for i in grp] == list(range(50)) and len(g) == 28
-    assert all(len(grp) == 1 or sum(2 * w[i] for i in grp) <= 128 for grp in g)
+    g = window_groups(w, 2048)                               # the 8-GPU headline bands: 256-row budget
+    assert [i for grp in g for i in grp] == list(range(50)) and len(g) == 12
+    assert all(len(grp) == 1 or sum(2 * w[i] for i in grp) <= 256 for grp in g)
+    assert len(window_groups(w, 8192)) == 6                  # 2 GPUs: 512 rows
     assert len(window_groups(w, 2048, 0)) == 50
     assert window_groups([0, 0, 3], 100) == [[0, 1, 2]]
     assert window_groups([], 100) == []
-    assert window_groups([40, 1], 100) == [[0], [1]]         # budget 64 -> 80 rows alone, then 2
+    assert window_groups([40, 1], 100) == [[0, 1]]           # budget = the band's 100 rows: 80 + 2 fit
+    assert window_groups([40, 20], 100) == [[0], [1]]        # 80 + 40 do not
 
 
 def test_band_rows_partition():
