@@ -15,15 +15,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=200)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--kinds", default="smrf,smrf,pf,inpaint,dem", help="comma list drawn from uniformly: smrf pf inpaint dem pssm fda")
 a = ap.parse_args()
 import neilpy_amd as nz  # noqa: E402
 from oracle import smrf_oracle as orc  # noqa: E402
 
 rng = np.random.default_rng(a.seed)
 bad = []
+counts = {}
 t0 = time.time()
 for k in range(a.cases):
-    kind = rng.choice(["smrf", "smrf", "pf", "inpaint", "dem"])
+    kind = str(rng.choice(a.kinds.split(",")))
+    counts[kind] = counts.get(kind, 0) + 1
     try:
         if kind == "smrf":
             npts = int(rng.integers(200, 6000))
@@ -78,6 +81,26 @@ for k in range(a.cases):
             if (st["istop"], st["itn"]) != (istop, itn) or np.abs(got - want).max(initial=0) > 1e-7:
                 bad.append((k, kind, dict(shape=shape, got=(st["istop"], st["itn"]), want=(istop, itn),
                                           err=float(np.abs(got - want).max(initial=0)))))
+        elif kind == "pssm":
+            shape = (int(rng.integers(2, 300)), int(rng.integers(2, 300)))
+            Z = rng.normal(0, 1, shape).cumsum(0).cumsum(1) * float(rng.choice([.01, .3, 5])) + 100
+            cs = float(rng.choice([1, .5, 2, 5, .3]))
+            ve = float(rng.choice([2.3, 1.0, 4.0]))
+            P = nz.pssm(Z, cellsize=cs, ve=ve, apply_colormap=False)
+            P2 = orc.pssm_classes(Z, cs, ve)
+            if not np.array_equal(P, P2):
+                bad.append((k, kind, dict(shape=shape, cs=cs, ve=ve, diff=int((P != P2).sum()))))
+        elif kind == "fda":
+            shape = (int(rng.integers(2, 70)), int(rng.integers(2, 70)))
+            A = rng.normal(0, 1, shape).cumsum(0).cumsum(1) * .1 + 100
+            A[rng.random(shape) >= rng.uniform(.3, .95)] = np.nan
+            want, istop, itn = orc.inpaint_nans_by_fda(A, return_info=True)
+            got = nz.inpaint_nans_by_fda(A)
+            st = nz.last_stats["inpaint_fda"]
+            scale = max(1.0, float(np.nanmax(np.abs(want)))) if np.isfinite(want).any() else 1.0
+            err = float(np.abs(got - want).max(initial=0)) / scale
+            if st["istop"] != istop or abs(st["itn"] - itn) > max(3, itn // 100) or not err <= 2e-5:
+                bad.append((k, kind, dict(shape=shape, got=(st["istop"], st["itn"]), want=(istop, itn), relerr=err)))
         else:
             npts = int(rng.integers(1, 4000))
             x0 = float(rng.choice([0, -250.5, 512345.0]))
@@ -95,6 +118,6 @@ for k in range(a.cases):
         bad.append((k, kind, "exception %r" % (e,)))
     if (k + 1) % 25 == 0:
         print("%d cases, %d bad, %.0f s" % (k + 1, len(bad), time.time() - t0), flush=True)
-print("DONE %d cases, %d bad" % (a.cases, len(bad)))
+print("DONE %d cases %s, %d bad" % (a.cases, counts, len(bad)))
 for b in bad[:40]:
     print("BAD", b)
