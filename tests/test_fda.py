@@ -52,7 +52,7 @@ def test_scipy_itself_moves_under_permutation():
         r = lsqr(a[p], b[p])
         assert r[1] == base[1] and abs(r[2] - base[2]) <= ITN_SLACK + 1
         moved = max(moved, float(np.abs(r[0] - base[0]).max()))
-    assert 1e-9 < moved / float(np.abs(base[0]).max()) < RTOL
+    assert 1e-12 < moved / float(np.abs(base[0]).max()) < RTOL
 
 
 def test_multiplicity_is_nan_entries_per_row():
