@@ -47,8 +47,9 @@ def record_dtype(fmt, record_length=None):
     return np.dtype(fields)
 
 
-def parse_header(data):
-    """Public header block -> dict with the reference's keys (neilpy.py:926-973)."""
+def parse_header(data, total_size=None):
+    """Public header block -> dict with the reference's keys (neilpy.py:926-973).  ``data`` may be the
+    file's first bytes only when ``total_size`` gives the file length."""
     u = struct.unpack_from
     h = {}
     h['file_signature'] = u('<4s', data, 0)[0].decode('utf-8')
@@ -77,7 +78,7 @@ def parse_header(data):
     h['scale'] = u('<3d', data, 131)
     h['offset'] = u('<3d', data, 155)
     h['minmax'] = u('<6d', data, 179)                 # xmax, xmin, ymax, ymin, zmax, zmin
-    end = len(data)
+    end = len(data) if total_size is None else total_size
     if h['version'] == 1.3:
         h['begin_wave_form'] = u('<q', data, 227)[0]
         if h['begin_wave_form'] != 0:
@@ -136,15 +137,53 @@ def read_las(filename):
     return header, data
 
 
+_STAGE_BYTES = 16 << 20
+_staging = {}
+
+
+def _staging_buffers():
+    """Two pinned host buffers (allocated once) the file is read into, chunk by chunk."""
+    import torch
+    if "bufs" not in _staging:
+        _staging["bufs"] = [torch.empty(_STAGE_BYTES, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+        _staging["events"] = [torch.cuda.Event() for _ in range(2)]
+    return _staging["bufs"], _staging["events"]
+
+
 def read_las_xyz(filename):
-    """``(header, x, y, z)`` with x, y, z float64 CUDA tensors decoded on the GPU from the raw records."""
+    """``(header, x, y, z)`` with x, y, z float64 CUDA tensors decoded on the GPU from the raw records.
+
+    The point records are streamed file -> pinned staging buffer -> device in 16 MB chunks (the read of
+    chunk k+1 overlaps the copy of chunk k), then one kernel applies scale and offset (neilpy.py:1055-1057)."""
     import ctypes as C
+    import os
     import torch
     from . import _lib
     _lib.require_gpu()
-    header, raw, reclen, npts = _load(filename)
+    size = os.path.getsize(filename)
     dev = torch.device("cuda", torch.cuda.current_device())
-    buf = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev) if npts else torch.empty(0, dtype=torch.uint8, device=dev)
+    with open(filename, mode='rb') as f:
+        header, end = parse_header(f.read(min(size, 1024)), total_size=size)
+        fmt = header['point_data_format_id']
+        reclen = max(header['point_data_record_length'], RECORD_SIZE[fmt])
+        start = header['point_data_offset']
+        npts = max(0, min(end, size) - start) // reclen
+        nbytes = npts * reclen
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        if nbytes:
+            stage, events = _staging_buffers()
+            f.seek(start)
+            pos = k = 0
+            while pos < nbytes:
+                n = min(_STAGE_BYTES, nbytes - pos)
+                events[k % 2].synchronize()                      # the copy that last used this buffer is done
+                got = f.readinto(memoryview(stage[k % 2].numpy())[:n])
+                if got != n:
+                    raise ValueError("LAS file truncated: expected %d more bytes of point records" % (n - got))
+                buf[pos:pos + n].copy_(stage[k % 2][:n], non_blocking=True)
+                events[k % 2].record()
+                pos += n
+                k += 1
     out = [torch.empty(npts, dtype=torch.float64, device=dev) for _ in range(3)]
     so = (C.c_double * 6)(*(list(header['scale']) + list(header['offset'])))
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -32,10 +32,11 @@ z = np.round(z + np.abs(rng.normal(0, 0.5, a.points)) * (rng.random(a.points) < 
 fn = os.path.join(tempfile.mkdtemp(), "dk22_standin.las")
 neilpy_amd.write_las(fn, x, y, z, fmt=1, scale=(0.01, 0.01, 0.01), offset=(864000.0, 1919000.0, 0.0))
 out = {"file_MB": round(os.path.getsize(fn) / 1e6, 1), "points": a.points, "cellsize": a.cellsize, "windows": a.windows}
-t0 = time.perf_counter()
-header, xd, yd, zd = neilpy_amd.read_las_xyz(fn)
-torch.cuda.synchronize()
-out["read_las_xyz_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+for rep in range(2):                                 # the first call also allocates the pinned staging buffers
+    t0 = time.perf_counter()
+    header, xd, yd, zd = neilpy_amd.read_las_xyz(fn)
+    torch.cuda.synchronize()
+    out["read_las_xyz_ms_run%d" % rep] = round((time.perf_counter() - t0) * 1e3, 1)
 for rep in range(2):
     t0 = time.perf_counter()
     dtm, T, obj, pts = neilpy_amd.smrf(xd, yd, zd, cellsize=a.cellsize, windows=a.windows)
