@@ -15,6 +15,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
+from ._xfer import to_device as _h2d, to_host as _d2h
 from .affine import from_origin
 
 __all__ = ["disk", "erosion", "dilation", "opening", "progressive_filter", "create_dem",
@@ -51,7 +52,7 @@ def _to_device(a, dtype=None):
         arr = np.asarray(a)
         if dtype is None and arr.dtype not in (np.float32, np.float64):
             arr = arr.astype(np.float64)
-        t = torch.from_numpy(np.ascontiguousarray(arr))
+        t = _h2d(arr)                                      # pinned staging for large arrays
     if dtype is not None and t.dtype != dtype:
         t = t.to(dtype)
     if t.dtype not in (torch.float32, torch.float64):
@@ -103,7 +104,7 @@ def _disk_filter(image, radius, dilate, impl, nan_aware=None):
     rows, cols = src.shape
     if rows == 0 or cols == 0:
         out = src.clone()
-        return out if was_tensor else out.cpu().numpy()
+        return out if was_tensor else _d2h(out)
     if nan_aware is None:
         nan_aware = _has_nan(src)
     out = torch.empty_like(src)
@@ -111,7 +112,7 @@ def _disk_filter(image, radius, dilate, impl, nan_aware=None):
     fn = getattr(lib, "smrf_disk_filter_" + _suffix(src))
     _lib.check(fn(_ptr(src), _ptr(out), rows, cols, cols, 0, rows, 0, rows, int(radius), int(bool(dilate)),
                   int(bool(nan_aware)), int(impl), _stream()))
-    return out if was_tensor else out.cpu().numpy()
+    return out if was_tensor else _d2h(out)
 
 
 def erosion(image, footprint=None, *, radius=None, impl=_lib.IMPL_AUTO):
@@ -132,7 +133,7 @@ def opening(image, footprint=None, *, radius=None, impl=_lib.IMPL_AUTO):
     nan_aware = _has_nan(src) if src.numel() else False
     e = _disk_filter(src, r, False, impl, nan_aware)
     o = _disk_filter(e, r, True, impl, nan_aware)
-    return o if was_tensor else o.cpu().numpy()
+    return o if was_tensor else _d2h(o)
 
 
 # ------------------------------------------------------------------------------------------
@@ -178,8 +179,8 @@ def progressive_filter(Z, windows, cellsize=1, slope_threshold=.15, return_when_
     if was_tensor:
         mask = mask.bool()
         return (mask, when) if return_when_dropped else mask
-    m = mask.cpu().numpy().astype(bool)
-    return (m, when.cpu().numpy()) if return_when_dropped else m
+    m = _d2h(mask).astype(bool)
+    return (m, _d2h(when)) if return_when_dropped else m
 
 
 # ------------------------------------------------------------------------------------------
@@ -263,7 +264,7 @@ def create_dem(x, y, z, cellsize=1, bin_type='max', inpaint=False, edges=None, u
     grid, _, t = _create_dem_device(xd, yd, zd, cellsize, bin_type, edges)
     if inpaint == True:  # noqa: E712  (the reference's own test, :1163)
         _springs_device(grid)
-    return (grid if was_tensor else grid.cpu().numpy()), t
+    return (grid if was_tensor else _d2h(grid)), t
 
 
 # ------------------------------------------------------------------------------------------
@@ -307,7 +308,7 @@ def inpaint_nans_by_springs(A, inplace=False, neighbors=4):
         raise ValueError("expected a 2-D raster")
     work = _to_device(arr.astype(np.float64, copy=False), torch.float64).clone()
     _springs_device(work)
-    out = work.cpu().numpy()
+    out = _d2h(work)
     if inplace:
         A[...] = out
         return None
@@ -360,7 +361,7 @@ def inpaint_nans_by_fda(A, fast=True, inplace=False):
         raise ValueError("negative dimensions are not allowed")      # the reference's np.ones(2*n*(m-2)) at :1190
     work = _to_device(arr.astype(np.float64, copy=False), torch.float64).clone()
     _fda_device(work)
-    out = work.cpu().numpy()
+    out = _d2h(work)
     if inplace:
         A[...] = out
         return None
@@ -459,21 +460,21 @@ def smrf(x, y, z, cellsize=1, windows=5, slope_threshold=.15, elevation_threshol
                              % (max(int(ri.max()), int(ci.max())), tuple(drop.shape)))
         extras = {'above_ground_height': zd - elev_d, 'drop_raster': drop, 'when_dropped': drop[ri, ci]}
         return Zpro_d, t, obj_t, pts_t, extras
-    Zpro = Zpro_d.cpu().numpy()
-    is_object_point = isobj_d.cpu().numpy().astype(bool)
+    Zpro = _d2h(Zpro_d)
+    is_object_point = _d2h(isobj_d).astype(bool)
     try:                                            # the reference returns a Series when z is one (:1795)
         import pandas as pd
         if isinstance(z, pd.Series):
             is_object_point = pd.Series(is_object_point, index=z.index, name=z.name)
     except ImportError:  # pragma: no cover
         pass
-    obj_np = object_cells.cpu().numpy().astype(bool)
+    obj_np = _d2h(object_cells).astype(bool)
     if not return_extras:
         return Zpro, t, obj_np, is_object_point
-    zh = z if not _is_tensor(z) else z.cpu().numpy()
-    elevation_values = elev_d.cpu().numpy()
-    drop_raster = drop.cpu().numpy()
-    r, c = r_d.cpu().numpy(), c_d.cpu().numpy()
+    zh = z if not _is_tensor(z) else _d2h(z)
+    elevation_values = _d2h(elev_d)
+    drop_raster = _d2h(drop)
+    r, c = _d2h(r_d), _d2h(c_d)
     extras = {'above_ground_height': zh - elevation_values, 'drop_raster': drop_raster,
               'when_dropped': drop_raster[np.round(r).astype(int), np.round(c).astype(int)]}
     return Zpro, t, obj_np, is_object_point, extras
@@ -487,7 +488,7 @@ class _DeviceValues:
 
     def __getitem__(self, key):
         if key not in self._np:
-            self._np[key] = self._t[key].cpu().numpy()
+            self._np[key] = _d2h(self._t[key])
         return self._np[key]
 
     def keys(self):
@@ -535,4 +536,4 @@ def pssm(Z, cellsize=1, ve=2.3, reverse=False, apply_colormap=True):
     _lib.check(lib.smrf_pssm_f64(_ptr(Zd), _ptr(P), _ptr(rgba), _ptr(lut), rows, cols, float(cellsize), float(ve),
                                  _stream()))
     out = rgba if apply_colormap else P
-    return out if was_tensor else out.cpu().numpy()
+    return out if was_tensor else _d2h(out)

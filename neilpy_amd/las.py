@@ -137,19 +137,6 @@ def read_las(filename):
     return header, data
 
 
-_STAGE_BYTES = 16 << 20
-_staging = {}
-
-
-def _staging_buffers():
-    """Two pinned host buffers (allocated once) the file is read into, chunk by chunk."""
-    import torch
-    if "bufs" not in _staging:
-        _staging["bufs"] = [torch.empty(_STAGE_BYTES, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
-        _staging["events"] = [torch.cuda.Event() for _ in range(2)]
-    return _staging["bufs"], _staging["events"]
-
-
 def read_las_xyz(filename):
     """``(header, x, y, z)`` with x, y, z float64 CUDA tensors decoded on the GPU from the raw records.
 
@@ -171,11 +158,12 @@ def read_las_xyz(filename):
         nbytes = npts * reclen
         buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         if nbytes:
-            stage, events = _staging_buffers()
+            from ._xfer import STAGE_BYTES, staging
+            stage, events = staging()
             f.seek(start)
             pos = k = 0
             while pos < nbytes:
-                n = min(_STAGE_BYTES, nbytes - pos)
+                n = min(STAGE_BYTES, nbytes - pos)
                 events[k % 2].synchronize()                      # the copy that last used this buffer is done
                 got = f.readinto(memoryview(stage[k % 2].numpy())[:n])
                 if got != n:
