@@ -18,3 +18,14 @@ for rep in range(3):
     print("run %d: smrf on %d NumPy points -> %s grid: %.1f ms (%.1f Mpoints/s), %d object points"
           % (rep, npts, out[0].shape, (time.perf_counter() - t0) * 1e3, npts / (time.perf_counter() - t0) / 1e6,
              int(np.sum(out[3]))), flush=True)
+
+# the headline workload through the NumPy boundary (PCIe-inclusive; never the bench's `value`)
+n = 16384
+Z = neilpy_amd.synth_dem(n, seed=20240)
+win = np.arange(1, 51)
+for rep in range(3):
+    t0 = time.perf_counter()
+    m = neilpy_amd.progressive_filter(Z, win, 1, .15)
+    dt = time.perf_counter() - t0
+    print("run %d: progressive_filter %dx%d fp32 NumPy in -> bool NumPy out: %.1f ms = %.0f Mcells/s (PCIe inclusive), %d objects"
+          % (rep, n, n, dt * 1e3, n * n / dt / 1e6, int(m.sum())), flush=True)
