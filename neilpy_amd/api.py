@@ -179,7 +179,7 @@ def progressive_filter(Z, windows, cellsize=1, slope_threshold=.15, return_when_
     if was_tensor:
         mask = mask.bool()
         return (mask, when) if return_when_dropped else mask
-    m = _d2h(mask).astype(bool)
+    m = _d2h(mask).view(np.bool_)                        # the kernels write 0 / 1
     return (m, _d2h(when)) if return_when_dropped else m
 
 
@@ -461,14 +461,14 @@ def smrf(x, y, z, cellsize=1, windows=5, slope_threshold=.15, elevation_threshol
         extras = {'above_ground_height': zd - elev_d, 'drop_raster': drop, 'when_dropped': drop[ri, ci]}
         return Zpro_d, t, obj_t, pts_t, extras
     Zpro = _d2h(Zpro_d)
-    is_object_point = _d2h(isobj_d).astype(bool)
+    is_object_point = _d2h(isobj_d).view(np.bool_)
     try:                                            # the reference returns a Series when z is one (:1795)
         import pandas as pd
         if isinstance(z, pd.Series):
             is_object_point = pd.Series(is_object_point, index=z.index, name=z.name)
     except ImportError:  # pragma: no cover
         pass
-    obj_np = _d2h(object_cells).astype(bool)
+    obj_np = _d2h(object_cells).view(np.bool_)
     if not return_extras:
         return Zpro, t, obj_np, is_object_point
     zh = z if not _is_tensor(z) else _d2h(z)
