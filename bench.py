@@ -3,8 +3,9 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--size 16384] [--windows 50]
 
-A "step" is one full progressive_filter call (all windows: erosion + dilation + flagging per
-window) over the synthetic DEM ``synth_dem(n, seed=20240)`` already resident in HBM.  With N > 1
+A "step" is one call of the public drop-in ``neilpy_amd.progressive_filter(Z, windows, cellsize,
+slope_threshold)`` (all windows: erosion + dilation + flagging per window, plus the call's own NaN
+scan and bool mask) over the synthetic DEM ``synth_dem(n, seed=20240)`` already resident in HBM.  With N > 1
 (launched by torch.distributed.run, one rank per GPU) the DEM's rows are split into N bands and
 groups of consecutive windows exchange their halo rows with the neighbouring ranks over RCCL
 (neilpy_amd/sharded.py): the problem size is fixed, so ``scaling`` is "strong".  Rank 0 prints ONE JSON line (see README / DESIGN.md).
@@ -107,7 +108,8 @@ def main():
 
     def step():
         if world == 1:
-            return api._progressive_filter_device(Z, windows, thresholds, False, nan_aware=0)[0]
+            # the drop-in entry itself (CUDA tensor in -> CUDA bool mask out), not an internal core
+            return neilpy_amd.progressive_filter(Z, windows, cellsize, slope)
         return sharded.progressive_filter_sharded(Z, n, windows, thresholds, rank=rank, world_size=world, state=state)[0]
 
     def barrier():
@@ -136,6 +138,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         dt, dev_ms, n_obj = float(tmax[0]), float(tmax[1]), int(t[2])
 
+    # the workload's known answer (tests/test_gpu_fullsize.py pins it): a run, sharded or not, that flags other cells
+    # is not a measurement.  Every rank holds the global count here, so every rank leaves with the same exit code.
+    expected = {(16384, 50, "f32"): 51388194}.get((n, a.windows, a.dtype))
+    if expected is not None and n_obj != expected:
+        if rank == 0:
+            print(json.dumps({"error": "object_cells %d != %d expected for this workload: the result is wrong, no bench "
+                                       "line is printed" % (n_obj, expected), "n_gpus": world}), file=sys.stderr, flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(2)
+
     # what a plain device copy of one plane reaches on this GPU (read + write), for context beside the 8 TB/s spec
     copy_gbps = None
     if rank == 0:
@@ -158,13 +171,17 @@ def main():
         avg_launch_s = dev_ms / 1e3 / a.steps / launches
         achieved = alg_bytes_launch / avg_launch_s / 1e9
         peak = 8000.0
-        traffic = None
+        # HBM bytes per launch come from rocprofv3 PMC passes, which cannot run inside this process: the committed
+        # summary of the same workload is quoted and labelled as such (tools/profile_round.sh regenerates it)
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
                 if rec.get("n") == n and rec.get("windows") == a.windows and rec.get("dtype") == a.dtype and world == 1:
                     traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_source = "profiles/pmc_summary.json (static: separate rocprofv3 --pmc passes, round %s)" \
+                                     % rec.get("round", "1")
             except Exception:  # noqa: BLE001
                 traffic = None
         out = {
@@ -172,13 +189,15 @@ def main():
             "value": cells / (dt / a.steps) / 1e6, "unit": "Mcells/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": "progressive_filter %dx%d %s, windows 1..%d, cellsize 1, slope_threshold 0.15, "
-                                   "synth_dem(seed=20240)" % (n, n, "fp32" if elem == 4 else "fp64", a.windows),
+            "config": {"workload": "%s %dx%d %s, windows 1..%d, cellsize 1, slope_threshold 0.15, synth_dem(seed=20240)"
+                                   % ("neilpy_amd.progressive_filter (public drop-in call, CUDA tensor in, bool mask out)"
+                                      if world == 1 else "sharded.progressive_filter_sharded (row bands)",
+                                      n, n, "fp32" if elem == 4 else "fp64", a.windows),
                        "sharding": "row bands x%d, one halo exchange per group of windows (%d per step, RCCL send/recv)"
                                    % (world, state.get("exchanges", 0)) if world > 1 else "single device",
                        "object_cells": n_obj},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-                         "traffic": traffic, "kernel": "smrf::ring_kernel (all radii; %d launches per step)" % launches,
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel": "smrf::ring_kernel (all radii; %d launches per step)" % launches,
                          "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": avg_launch_s * 1e3,
                          "device_copy_gbps": copy_gbps, "frac_of_device_copy": achieved / copy_gbps},
         }

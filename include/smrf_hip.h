@@ -17,6 +17,7 @@
  *   smrf_springs_lsqr_f64     inpaint_nans_by_springs(), neilpy/neilpy.py:1227-1271, whose
  *                             solve is scipy.sparse.linalg.lsqr (:1264)
  *   smrf_fda_lsqr_f64         inpaint_nans_by_fda(), neilpy/neilpy.py:1170-1216
+ *   smrf_fda_apply_f64        (diagnostic) the same operator applied once, for the structural parity test
  *   smrf_gradient_slope_f64   np.gradient + sqrt, neilpy/neilpy.py:1785-1786
  *   smrf_pssm_f64             pssm(), neilpy/neilpy.py:846-867
  *   smrf_las_decode_xyz_f64   the coordinate decode of read_las(), neilpy/neilpy.py:903-1087 (host
@@ -178,15 +179,16 @@ SMRF_API int smrf_springs_lsqr_f64(double* d_A, int rows, int cols, double atol,
 /* Row-band form of the same solver for rasters sharded over several GPUs.  The band
  * holds rows_local x cols cells of d_A_band.  The workspace keeps every plane with one halo row
  * above and one below; smrf_springs_band_layout() gives the byte offsets the host needs to
- * exchange halo rows and to all-reduce the one scalar between phases:
+ * exchange halo rows and to all-reduce the phase sums:
  *   h_out[0] v plane, h_out[1] uv plane (rows_local + 2 rows of cols doubles, row 0 = halo above),
  *   h_out[2] hole plane (rows_local + 2 rows of cols bytes), h_out[3] cols doubles = raster row
- *   below the band, h_out[4] one double = the phase's local sum, h_out[5] total bytes.
+ *   below the band, h_out[4] two doubles = the phase's local sums (phase 3 fills both: |v|^2 and |w|^2,
+ *   to be all-reduced as ONE 2-element buffer; every other phase uses the first), h_out[5] total bytes.
  * Phases (in order; "<- X" = what the host must have delivered before the phase):
  *   0 mask+count | 1 rhs <- hole halo below, A row below, all-reduced count | 2 |b| <- all-reduce
  *   3 v = S^T u - beta v <- uv halo above | 4 first alfa, w <- all-reduce
- *   loop: 5 u = S v - alfa u <- v halo below | 6 beta <- all-reduce | 3 | 7 alfa + rotation <- all-reduce
- *         8 x, w update | 9 stopping tests <- all-reduce
+ *   loop: 5 u = S v - alfa u <- v halo below | 6 beta <- all-reduce | 3 | 7 alfa + rotation <- all-reduce (2 values)
+ *         8 x, w update | 9 stopping tests (|dk|^2 = |w|^2 / rho^2 from phase 3's second sum: no collective)
  *   10 scatter the solution into d_A_band.
  * neilpy_amd/sharded.py drives it over torch.distributed (RCCL). */
 SMRF_API size_t smrf_springs_band_workspace_bytes(int rows_local, int cols);
@@ -208,6 +210,14 @@ SMRF_API size_t smrf_fda_workspace_bytes(int rows, int cols);
 SMRF_API int smrf_fda_lsqr_f64(double* d_A, int rows, int cols, double atol, double btol, double conlim,
                       int64_t iter_lim, int* h_istop, int64_t* h_itn, int64_t* h_n_unknown,
                       void* d_workspace, size_t workspace_bytes, void* stream);
+/* Diagnostic (tests): one application of the operator smrf_fda_lsqr_f64 iterates with, against the
+ * reference's explicit sparse system (neilpy/neilpy.py:1180-1209).  All buffers are rows x cols rasters on
+ * the device: d_rhs / d_cnt <- right-hand side and multiplicity (NaN entries, :1207-1209) of every
+ * equation cell; d_Av <- A v on the equation cells (v read on the NaN cells of d_A); d_Atu <- A^T u on the
+ * NaN cells (u read on the equation cells, each counted d_cnt times).  Workspace as smrf_fda_workspace_bytes. */
+SMRF_API int smrf_fda_apply_f64(const double* d_A, int rows, int cols, const double* d_v, const double* d_u,
+                      double* d_rhs, uint8_t* d_cnt, double* d_Av, double* d_Atu, void* d_workspace,
+                      size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * smrf tail

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libsmrf_hip.so")
+# NEILPY_AMD_LIB: another build of the same library (developer A/B runs of bench.py on one box; never a CPU path)
+LIB_PATH = os.environ.get("NEILPY_AMD_LIB") or os.path.join(_HERE, "_lib", "libsmrf_hip.so")
 
 IMPL_AUTO, IMPL_RING, IMPL_DIRECT = 0, 1, 2
 RING_MAX_RADIUS = 64
@@ -49,6 +50,7 @@ SIGNATURES = {
     "smrf_fda_workspace_bytes": (_sz, [_i, _i]),
     "smrf_fda_lsqr_f64": (_i, [_p, _i, _i, _d, _d, _d, _i64, C.POINTER(_i), C.POINTER(_i64),
                                C.POINTER(_i64), _p, _sz, _p]),
+    "smrf_fda_apply_f64": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "smrf_springs_band_workspace_bytes": (_sz, [_i, _i]),
     "smrf_springs_band_layout": (_i, [_i, _i, C.POINTER(_i64)]),
     "smrf_springs_band_begin": (_i, [_i, _i, _d, _d, _d, _i64, _p, _sz, _p]),

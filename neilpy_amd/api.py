@@ -15,6 +15,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
+from ._device import device_scoped as _device_scoped, is_tensor as _is_tensor
 from ._xfer import to_device as _h2d, to_host as _d2h
 from .affine import from_origin
 
@@ -36,10 +37,6 @@ def _stream():
 
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
-
-
-def _is_tensor(a):
-    return type(a).__module__.startswith("torch") and hasattr(a, "data_ptr")
 
 
 def _to_device(a, dtype=None):
@@ -115,16 +112,19 @@ def _disk_filter(image, radius, dilate, impl, nan_aware=None):
     return out if was_tensor else _d2h(out)
 
 
+@_device_scoped
 def erosion(image, footprint=None, *, radius=None, impl=_lib.IMPL_AUTO):
     """Grey erosion by ``disk(r)``, borders ``mode='reflect'`` (scipy.ndimage.grey_erosion)."""
     return _disk_filter(image, _radius_of(footprint, radius), False, impl)
 
 
+@_device_scoped
 def dilation(image, footprint=None, *, radius=None, impl=_lib.IMPL_AUTO):
     """Grey dilation by ``disk(r)``, borders ``mode='reflect'`` (scipy.ndimage.grey_dilation)."""
     return _disk_filter(image, _radius_of(footprint, radius), True, impl)
 
 
+@_device_scoped
 def opening(image, footprint=None, *, radius=None, impl=_lib.IMPL_AUTO):
     """skimage.morphology.opening(image, disk(r)) = dilation(erosion(image))."""
     r = _radius_of(footprint, radius)
@@ -160,6 +160,7 @@ def _progressive_filter_device(Zd, windows, thresholds, want_when, impl=_lib.IMP
     return mask, when
 
 
+@_device_scoped
 def progressive_filter(Z, windows, cellsize=1, slope_threshold=.15, return_when_dropped=False, *,
                        impl=_lib.IMPL_AUTO):
     """Iterative grey opening with growing disks and slope-scaled thresholds -> object mask.
@@ -250,6 +251,7 @@ def _points_to_device(x, y, z):
     return xd, yd, zd
 
 
+@_device_scoped
 def create_dem(x, y, z, cellsize=1, bin_type='max', inpaint=False, edges=None, use_binned_statistic=False):
     """Grid (x, y, z) points to a min-/max-Z raster; empty cells are NaN.  Returns ``(I, t)``.
 
@@ -286,6 +288,7 @@ def _springs_device(Ad, key="inpaint"):
     return istop.value, itn.value
 
 
+@_device_scoped
 def inpaint_nans_by_springs(A, inplace=False, neighbors=4):
     """Fill NaNs by least-squares springs to the 4 neighbours, stopped where SciPy's LSQR stops.
 
@@ -334,6 +337,7 @@ def _fda_device(Ad, key="inpaint_fda"):
     return istop.value, itn.value
 
 
+@_device_scoped
 def inpaint_nans_by_fda(A, fast=True, inplace=False):
     """Fill NaNs by least squares on the second-difference equations, stopped where SciPy's LSQR stops.
 
@@ -408,6 +412,7 @@ def _classify_points_device(Zpro_d, t, cellsize, xd, yd, zd, elevation_threshold
     return elev_d, slope_d, isobj_d, r_d, c_d
 
 
+@_device_scoped
 def smrf(x, y, z, cellsize=1, windows=5, slope_threshold=.15, elevation_threshold=.5,
          elevation_scaler=1.25, low_filter_slope=5, low_outlier_fill=False,
          return_extras=False):
@@ -444,8 +449,11 @@ def smrf(x, y, z, cellsize=1, windows=5, slope_threshold=.15, elevation_threshol
     Zpro_d = Zmin
     elev_d, slope_d, isobj_d, r_d, c_d = _classify_points_device(Zpro_d, t, cellsize, xd, yd, zd, elevation_threshold,
                                                                  elevation_scaler)
-    # diagnostics stay on the device until somebody reads them (tests compare them with FITPACK's values)
-    last_stats["tail"] = _DeviceValues(elevation_values=elev_d, slope_values=slope_d)
+    # the spline values are diagnostics (tests compare them with FITPACK's); 16 B per point of HBM, so they are only
+    # kept alive past the call when the caller asked for the extras
+    last_stats.pop("tail", None)
+    if return_extras:
+        last_stats["tail"] = _DeviceValues(elevation_values=elev_d, slope_values=slope_d)
     if _is_tensor(x) and _is_tensor(y) and _is_tensor(z):
         # CUDA tensors in -> CUDA tensors out: nothing of the result crosses PCIe
         obj_t, pts_t = object_cells.bool(), isobj_d.bool()
@@ -504,6 +512,7 @@ class _DeviceValues:
 _lut_cache = {}
 
 
+@_device_scoped
 def pssm(Z, cellsize=1, ve=2.3, reverse=False, apply_colormap=True):
     """Perceptually scaled slope map, same arguments and results as neilpy.pssm.
 

@@ -327,4 +327,49 @@ int smrf_fda_lsqr_f64(double* d_A, int rows, int cols, double atol, double btol,
   return SMRF_OK;
 }
 
+// Diagnostic entry (tests only; not used by inpaint_nans_by_fda): the operator the solver iterates with, applied
+// once.  d_rhs / d_cnt receive the right-hand side and the multiplicity of every equation cell, d_Av = A v on the
+// equation cells (v read on the NaN cells of d_A), d_Atu = A^T u on the NaN cells (u read on the equation cells,
+// every equation counted cnt times).  tests/test_fda.py compares them with the reference's explicit sparse
+// system (neilpy.py:1180-1209) so that the LSQR iteration-count tolerance is not the only guard on the stencils.
+int smrf_fda_apply_f64(const double* d_A, int rows, int cols, const double* d_v, const double* d_u, double* d_rhs,
+                       uint8_t* d_cnt, double* d_Av, double* d_Atu, void* d_workspace, size_t workspace_bytes,
+                       void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!d_A || !d_v || !d_u || !d_rhs || !d_cnt || !d_Av || !d_Atu) return smrf_fail(SMRF_E_ARG, "null pointer");
+  if (rows < 1 || cols < 1) return smrf_fail(SMRF_E_ARG, "bad raster size %d x %d", rows, cols);
+  const FdaLayout L = fda_layout(rows, cols);
+  if (!d_workspace || workspace_bytes < L.total) return smrf_fail(SMRF_E_WORKSPACE, "fda workspace too small");
+  char* p = (char*)d_workspace;
+  Fda b;
+  b.x = (double*)(p + L.x); b.v = (double*)(p + L.v); b.w = (double*)(p + L.w); b.u = (double*)(p + L.u);
+  b.hole = (uint8_t*)(p + L.hole); b.cnt = (uint8_t*)(p + L.cnt);
+  b.part = (double*)(p + L.part); b.red = (double*)(p + L.red); b.sc = (Sc*)(p + L.sc);
+  b.rows = rows; b.cols = cols;
+  Sc h{};
+  h.cs2 = -1.0; h.iter_lim = -1;
+  h.inv_alfa = 1.0; h.inv_beta = 1.0; h.beta_pos = 1;     // alfa = beta = 0: the kernels compute the bare products
+  SMRF_HIP_CHECK(hipMemcpyAsync(b.sc, &h, sizeof(h), hipMemcpyHostToDevice, stream));
+  SMRF_HIP_CHECK(hipStreamSynchronize(stream));
+  const size_t n = (size_t)rows * cols;
+  const int nb1 = (int)std::max<long long>(1, std::min<long long>(((long long)n + 255) / 256, MAXB));
+  const int cb = (cols + 255) / 256;
+  const dim3 g2(cb, std::max(1, std::min(rows, MAXB / std::max(cb, 1))));
+  hipLaunchKernelGGL(fda_mask_kernel, dim3(nb1), dim3(256), 0, stream, d_A, b);
+  hipLaunchKernelGGL(fda_rhs_kernel, g2, dim3(256), 0, stream, d_A, b);
+  SMRF_LAUNCH_CHECK();
+  SMRF_HIP_CHECK(hipMemcpyAsync(d_rhs, b.u, n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+  SMRF_HIP_CHECK(hipMemcpyAsync(d_cnt, b.cnt, n, hipMemcpyDeviceToDevice, stream));
+  SMRF_HIP_CHECK(hipMemcpyAsync(b.v, d_v, n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+  hipLaunchKernelGGL(fda_av_kernel, g2, dim3(256), 0, stream, b);          // u = A v - 0 * u
+  SMRF_LAUNCH_CHECK();
+  SMRF_HIP_CHECK(hipMemcpyAsync(d_Av, b.u, n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+  SMRF_HIP_CHECK(hipMemcpyAsync(b.u, d_u, n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+  hipLaunchKernelGGL(fda_atu_kernel, g2, dim3(256), 0, stream, b);         // v = A^T u - 0 * v
+  SMRF_LAUNCH_CHECK();
+  SMRF_HIP_CHECK(hipMemcpyAsync(d_Atu, b.v, n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+  SMRF_HIP_CHECK(hipStreamSynchronize(stream));
+  return SMRF_OK;
+}
+
 }  // extern "C"

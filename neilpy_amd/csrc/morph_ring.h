@@ -30,13 +30,23 @@
 
 #include "smrf_common.h"
 
-#ifndef SMRF_RING_TW
-#define SMRF_RING_TW 256   // columns (= lanes) per workgroup: 256 (shared table, barriers) or 64 (wave-private)
-#endif
 // lookup groups in flight: a third buffer (+16 VGPRs in fp32) only where the kernel sits at 2 waves/SIMD
 // anyway (demand above 168 VGPRs) and the extra registers do not cost a wave
+// lookup groups in flight.  Measured in both rounds: a third group in flight gains nothing at any radius and costs a
+// wave at some (R = 28: 0.873 vs 0.838 ms, gpurun_out/r02/probe_exp2.log) - lookup latency is not what the consume
+// phase waits for.
 #ifndef SMRF_RING_DEPTH
-#define SMRF_RING_DEPTH(need) 2   /* measured: a third group in flight gains nothing (lookups are not the exposed latency) */
+#define SMRF_RING_DEPTH(need) 2
+#endif
+#ifndef SMRF_RING_BUILD_PRIO
+#define SMRF_RING_BUILD_PRIO 3
+#endif
+// columns (= lanes) per workgroup: 256 (shared table, barriers); tuning builds may fix 64 (wave-private table) or 512
+// (fp32 only) with -DSMRF_RING_TW=n
+#ifdef SMRF_RING_TW
+#define SMRF_RING_TW_OF(T, R) SMRF_RING_TW
+#else
+#define SMRF_RING_TW_OF(T, R) ring_tuned_tw<T>(R)
 #endif
 // lookups per pipelined group: 4 for the small disks; 2 or 3 for the large ones, whose ring leaves
 // few registers for lookups in flight (measured per radius: tools/ring_tune.py --variants cur,g2,g3,g6)
@@ -69,6 +79,10 @@ constexpr int ring_occ_drop(int occ, int steps) {
 }
 
 #include "ring_tune.inc"
+
+// columns per workgroup per radius: 256 everywhere (512-column workgroups, one per CU, measured within +-1 % of 256 at
+// R >= 39 and 20-25 % slower below: gpurun_out/r02/probe_tw512.log)
+template <typename T> constexpr int ring_tuned_tw(int) { return 256; }
 
 constexpr int clog2(int v) {  // floor(log2(v)), v >= 1
   int l = 0;
@@ -248,7 +262,7 @@ constexpr int ring_np() {
   if constexpr (mx >= 2) if (RingCfg<T, R, TW, 2>::WG_LDS >= want) return 2;
   return 1;
 }
-#define SMRF_RING_NP(T, R) ring_np<T, R, SMRF_RING_TW>()
+#define SMRF_RING_NP(T, R) ring_np<T, R, SMRF_RING_TW_OF(T, R)>()
 
 // Diagnostic build only (-DSMRF_STAMPS): per-phase wave-cycle sums, written to a buffer of their own
 // (never read by the kernel, never part of an output).  Not compiled into the product library.
@@ -293,7 +307,7 @@ struct RowFold {
 };
 
 template <typename T, int R, bool DIL, int TW, int NP>
-__global__ __launch_bounds__(TW, (SMRF_OCC_OVERRIDE(RingCfg<T, R, TW, NP>::OCC)))
+__global__ __launch_bounds__(TW, (SMRF_OCC_OVERRIDE(TW > 256 ? (RingCfg<T, R, TW, NP>::OCC * 256 / TW < 1 ? 1 : RingCfg<T, R, TW, NP>::OCC * 256 / TW) : RingCfg<T, R, TW, NP>::OCC)))
 void ring_kernel(const DiskArgs<T> a) {
   using C = RingCfg<T, R, TW, NP>;
   using S = typename C::S;
@@ -456,6 +470,10 @@ void ring_kernel(const DiskArgs<T> a) {
     load_last(yy0);
     SMRF_STAMP(3);                                         // issue of next loads
 
+    // the build phases end in barriers the whole workgroup waits at: let a wave in them win the issue arbitration
+    // against the SIMD's other wave (which is usually consuming); measured -3...-5.5 % at every radius >= 8
+    __builtin_amdgcn_s_setprio(SMRF_RING_BUILD_PRIO);
+#ifndef SMRF_EXP_NOBUILD
     // (2) base level JB from level 0: 2^JB - 1 independent reads per cell.  All reads of the
     //     batch are issued first (asm ds_read_b64: hipcc would fuse them into half-rate
     //     ds_read2_b64), then one wait, then the min/max and the writes.
@@ -496,29 +514,27 @@ void ring_kernel(const DiskArgs<T> a) {
     SMRF_STAMP(4);                                         // base level
     phase_sync();
     SMRF_STAMP(5);                                         // barrier 2
-    // (3) levels JB+1 .. J from the base level: cells pos + k * 2^JB, k < 2^(J-JB)
+    // (3) levels JB+1 .. J from the base level: cells pos + k * 2^JB, k < 2^(J-JB).  One job per (cell position,
+    //     row pair): NB independent reads, then the min/max chain and the stores.  Jobs are software-pipelined two
+    //     deep (the next job's reads are issued before this job's wait), within the 15 LDS operations a wave may have
+    //     outstanding; round 1 drained every job on its own and spent 14 % of the R = 50 wave time here.
     if constexpr (J > JB) {
       constexpr int NB = (1 << (J - JB)) - 1;
-      constexpr int PG = (NP * NB * C::E > 16) ? 1 : NP;        // pairs whose reads are in flight together
+      constexpr int NBUF = (2 * NB <= 15 && NP > 1) ? 2 : 1;
 #pragma unroll
       for (int i = 0; i < NPOS; ++i) {
         if (i < NPOS - 1 || has_last) {
-         const int pos = tid + i * TW;
-#pragma unroll
-         for (int p0 = 0; p0 < NP; p0 += PG) {
-          T2 nb[PG][NB];
-#pragma unroll
-          for (int p = p0; p < p0 + PG; ++p) {
-            const unsigned ad = lds_l + ((p * NLEV + SB) * WP + i * TW) * (unsigned)sizeof(T2);
+          const int pos = tid + i * TW;
+          T2 nb[NBUF][NB];
+          auto issue_job = [&]<int P>(std::integral_constant<int, P>) {
+            const unsigned ad = lds_l + ((P * NLEV + SB) * WP + i * TW) * (unsigned)sizeof(T2);
             [&]<int... Kk>(std::integer_sequence<int, Kk...>) {
-              ((nb[p - p0][Kk] = lds_read2<((Kk + 1) << JB) * (int)sizeof(T2)>(ad, T())), ...);
+              ((nb[P % NBUF][Kk] = lds_read2<((Kk + 1) << JB) * (int)sizeof(T2)>(ad, T())), ...);
             }(std::make_integer_sequence<int, NB>{});
-          }
-          lds_wait<0>();
-#pragma unroll
-          for (int p = p0; p < p0 + PG; ++p) {
-            const T2* n = nb[p - p0];
-            T2 m = v[p][i];
+          };
+          auto finish_job = [&]<int P>(std::integral_constant<int, P>) {
+            const T2* n = nb[P % NBUF];
+            T2 m = v[P][i];
             [&]<int... JJ>(std::integer_sequence<int, JJ...>) {
               (([&] {
                  constexpr int j = JB + 1 + JJ;            // level being completed
@@ -532,13 +548,26 @@ void ring_kernel(const DiskArgs<T> a) {
                  }
                  if constexpr (C::stored(j)) {
                    constexpr int sj = C::slot_of(j);
-                   L[(p * NLEV + sj) * WP + pos] = m;
+                   L[(P * NLEV + sj) * WP + pos] = m;
                  }
                }()), ...);
             }(std::make_integer_sequence<int, J - JB>{});
-          }
-          __builtin_amdgcn_sched_barrier(0);
-         }
+          };
+          if constexpr (NBUF == 2) issue_job(std::integral_constant<int, 0>{});
+          [&]<int... P>(std::integer_sequence<int, P...>) {
+            (([&] {
+               if constexpr (NBUF == 2) {
+                 // the stores of job P-1 were issued before these reads: in-order completion covers them too
+                 if constexpr (P + 1 < NP) issue_job(std::integral_constant<int, P + 1>{});
+                 lds_wait<(P + 1 < NP ? NB : 0)>();
+               } else {
+                 issue_job(std::integral_constant<int, P>{});
+                 lds_wait<0>();
+               }
+               finish_job(std::integral_constant<int, P>{});
+               __builtin_amdgcn_sched_barrier(0);
+             }()), ...);
+          }(std::make_integer_sequence<int, NP>{});
         }
       }
       SMRF_STAMP(6);                                       // higher levels
@@ -546,7 +575,13 @@ void ring_kernel(const DiskArgs<T> a) {
       SMRF_STAMP(7);                                       // barrier 3
     }
 
+#endif  // SMRF_EXP_NOBUILD
+    __builtin_amdgcn_s_setprio(0);
+#ifdef SMRF_EXP_NOCONSUME
+    if (a.seg < 0)   // never true: keeps the consume code (and its registers) in the kernel, skips it at run time
+#endif
     // (4) consume: window lookups + ring update, pair by pair
+    {
     T2 own[NP];                                            // the lane's own cells (level 0)
 #pragma unroll
     for (int p = 0; p < NP; ++p)
@@ -619,6 +654,7 @@ void ring_kernel(const DiskArgs<T> a) {
       __builtin_amdgcn_sched_barrier(0);
       SMRF_STAMP(8);                                       // lookups + ring update of one pair
     }
+    }
   }
   SMRF_STAMP_FLUSH
   {
@@ -629,7 +665,7 @@ void ring_kernel(const DiskArgs<T> a) {
 
 template <typename T, int R, bool DIL>
 int ring_launch(const DiskArgs<T>& a_in, hipStream_t stream) {
-  constexpr int TW = SMRF_RING_TW;
+  constexpr int TW = SMRF_RING_TW_OF(T, R);
   constexpr int NP = SMRF_RING_NP(T, R);
   using C = RingCfg<T, R, TW, NP>;
   auto kern = ring_kernel<T, R, DIL, TW, NP>;

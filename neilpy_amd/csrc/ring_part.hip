@@ -1,6 +1,10 @@
 // Instantiates the register-ring kernels for the radii r with r % SMRF_RING_PARTS == PART
 // (compiled once per PART and per dtype so the 64 x 2 x 2 kernels build in parallel).
 //   hipcc ... -DPART=k -DSMRF_F64=0|1 -c ring_part.hip
+#if defined(SMRF_RING_TW) && SMRF_F64 && SMRF_RING_TW > 256
+#undef SMRF_RING_TW            // tuning builds with 512-column strips: fp32 only (LDS offsets of the fp64 table exceed 16 bits)
+#define SMRF_RING_TW 256
+#endif
 #include "morph_ring.h"
 
 #ifndef PART

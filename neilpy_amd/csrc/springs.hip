@@ -37,6 +37,7 @@ struct Band {
   int rows, cols, has_above, has_below;
 };
 
+
 // ---- setup ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mask_kernel(const double* __restrict__ A, const Band b) {
   __shared__ double red[4];
@@ -102,14 +103,19 @@ __global__ void s_bnorm(const Band b) {
 }
 
 // ---- v = S^T u_s - beta * v_s  (u_s = inv_beta*u, v_s = inv_alfa*v), partial |v|^2 -----------
+// WSUM (row-band form): also the partial |w|^2 of the same cells -> part[MAXB..].  w is still the vector the
+// iteration's dk = w / rho is made of, so |dk|^2 = |w|^2 / rho^2 can ride with |v|^2 in ONE 2-element all-reduce
+// instead of a third collective after the x, w update (rho only exists once |v|^2 is reduced).
+template <bool WSUM>
 __global__ __launch_bounds__(256) void atu_kernel(const Band b) {
   __shared__ double red[4];
+  __shared__ double red2[4];
   const Sc* sc = b.sc;
   if (stopped(sc) || !sc->beta_pos) return;
   const double ib = sc->inv_beta, ia = sc->inv_alfa, beta = sc->beta;
   const int rows = b.rows, cols = b.cols;
   const long long n = (long long)rows * cols;
-  double s = 0.0;
+  double s = 0.0, sw = 0.0;
   SMRF_FOR_CELLS(rows, cols) {
     if (!b.hole[i]) continue;
     double y = 0.0;
@@ -120,9 +126,25 @@ __global__ __launch_bounds__(256) void atu_kernel(const Band b) {
     const double nv = y - beta * (ia * b.v[i]);
     b.v[i] = nv;
     s += nv * nv;
+    if constexpr (WSUM) { const double ws = b.w[i]; sw += ws * ws; }
   }
   const double t = block_sum(s, red);
   if (threadIdx.x == 0) b.part[blockIdx.y * gridDim.x + blockIdx.x] = t;
+  if constexpr (WSUM) {
+    const double tw = block_sum(sw, red2);
+    if (threadIdx.x == 0) b.part[MAXB + blockIdx.y * gridDim.x + blockIdx.x] = tw;
+  }
+}
+
+// block partials of two sums -> red[0], red[1]
+__global__ __launch_bounds__(256) void reduce2_kernel(const double* __restrict__ part, int nb, double* __restrict__ out) {
+  __shared__ double red[4];
+  __shared__ double red2[4];
+  double s0 = 0.0, s1 = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256) { s0 += part[i]; s1 += part[MAXB + i]; }
+  const double t0 = block_sum(s0, red);
+  const double t1 = block_sum(s1, red2);
+  if (threadIdx.x == 0) { out[0] = t0; out[1] = t1; }
 }
 
 __global__ void s_init_alfa(const Band b) {
@@ -153,6 +175,9 @@ __global__ __launch_bounds__(256) void av_kernel(const Band b) {
   const long long n = (long long)rows * cols;
   double s = 0.0;
   SMRF_FOR_CELLS(rows, cols) {
+    // v[i] is read before the hole tests on purpose: making it (or a per-tile activity byte) conditional turns
+    // independent loads into dependent ones and measured 4-10 % SLOWER on 8192^2 at every hole pattern
+    // (gpurun_out/r02/lsqr_ab*.log); planes of known-only regions are never touched as it is.
     const bool h0 = b.hole[i];
     const double v0 = ia * b.v[i];
     if (c + 1 < cols) {
@@ -204,9 +229,10 @@ __global__ __launch_bounds__(256) void xw_kernel(const Band b) {
   if (threadIdx.x == 0) b.part[blockIdx.y * gridDim.x + blockIdx.x] = t;
 }
 
+// row-band form: red[1] = all-reduced |w|^2 from the ATU phase; |dk|^2 = |w|^2 / rho^2
 __global__ void s_tests(const Band b) {
   if (stopped(b.sc)) return;
-  tests_step(b.sc, b.red[0]);
+  tests_step(b.sc, (b.red[1] * b.sc->inv_rho) * b.sc->inv_rho);
 }
 
 // ---- single-device fast path: xw of iteration i fused with av of iteration i+1 ---------------
@@ -223,7 +249,7 @@ __global__ __launch_bounds__(256) void xwav_kernel(const Band b) {
   double sd = 0.0, su = 0.0;
   SMRF_FOR_CELLS(rows, cols) {
     const bool h0 = b.hole[i];
-    const double v0 = ia * b.v[i];
+    const double v0 = ia * b.v[i];                       // unconditional on purpose (see av_kernel)
     if (h0) {
       const double ws = b.w[i];
       const double dk = ir * ws;
@@ -308,13 +334,13 @@ enum Phase {
   PH_MASK = 0,      // hole mask of own rows, red[0] = local unknown count
   PH_RHS = 1,       // (after hole/A halo + count all-reduce) rhs, red[0] = local |b|^2
   PH_BNORM = 2,     // (after all-reduce) beta = |b|
-  PH_ATU = 3,       // (after uv halo)  v = S^T u - beta v, red[0] = local |v|^2
+  PH_ATU = 3,       // (after uv halo)  v = S^T u - beta v, red[0] = local |v|^2, red[1] = local |w|^2
   PH_INIT_ALFA = 4, // (after all-reduce) alfa, w = v
   PH_AV = 5,        // (after v halo)   u = S v - alfa u, red[0] = local |u|^2
   PH_BETA = 6,      // (after all-reduce)
   PH_ALFA_ROT = 7,  // (after PH_ATU + all-reduce) alfa, plane rotation
-  PH_XW = 8,        // x, w update, red[0] = local |w/rho|^2
-  PH_TESTS = 9,     // (after all-reduce) stopping tests, itn += 1
+  PH_XW = 8,        // x, w update
+  PH_TESTS = 9,     // stopping tests (|dk|^2 = red[1] / rho^2, reduced with PH_ATU's pair), itn += 1
   PH_SCATTER = 10,  // A[hole] = x
 };
 
@@ -338,7 +364,10 @@ int run_phase(int phase, double* A, const Band& b, hipStream_t st) {
       reduce(nb2);
       break;
     case PH_BNORM: hipLaunchKernelGGL(s_bnorm, dim3(1), dim3(1), 0, st, b); break;
-    case PH_ATU: hipLaunchKernelGGL(atu_kernel, g2, dim3(256), 0, st, b); reduce(nb2); break;
+    case PH_ATU:
+      hipLaunchKernelGGL(atu_kernel<true>, g2, dim3(256), 0, st, b);
+      hipLaunchKernelGGL(reduce2_kernel, dim3(1), dim3(256), 0, st, (const double*)b.part, nb2, b.red);
+      break;
     case PH_INIT_ALFA:
       hipLaunchKernelGGL(s_init_alfa, dim3(1), dim3(1), 0, st, b);
       hipLaunchKernelGGL(w_init_kernel, dim3(nb), dim3(256), 0, st, b);
@@ -346,7 +375,7 @@ int run_phase(int phase, double* A, const Band& b, hipStream_t st) {
     case PH_AV: hipLaunchKernelGGL(av_kernel, g2, dim3(256), 0, st, b); reduce(nb2); break;
     case PH_BETA: hipLaunchKernelGGL(s_beta, dim3(1), dim3(1), 0, st, b); break;
     case PH_ALFA_ROT: hipLaunchKernelGGL(s_alfa_rot, dim3(1), dim3(1), 0, st, b); break;
-    case PH_XW: hipLaunchKernelGGL(xw_kernel, dim3(nb), dim3(256), 0, st, b); reduce(nb); break;
+    case PH_XW: hipLaunchKernelGGL(xw_kernel, dim3(nb), dim3(256), 0, st, b); break;   // its sum rode with PH_ATU's
     case PH_TESTS: hipLaunchKernelGGL(s_tests, dim3(1), dim3(1), 0, st, b); break;
     case PH_SCATTER: hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, st, A, b); break;
     default: return smrf_fail(SMRF_E_ARG, "unknown springs phase %d", phase);
@@ -398,7 +427,7 @@ int smrf_springs_lsqr_f64(double* d_A, int rows, int cols, double atol, double b
   int chunk = 4;
   while (!out.done && out.istop == 0 && out.itn < lim) {
     for (int k = 0; k < chunk; ++k) {
-      hipLaunchKernelGGL(atu_kernel, g2, dim3(256), 0, stream, b);
+      hipLaunchKernelGGL(atu_kernel<false>, g2, dim3(256), 0, stream, b);
       hipLaunchKernelGGL((reduce_scalar_kernel<1, Band>), dim3(1), dim3(256), 0, stream, b, nb);
       hipLaunchKernelGGL(xwav_kernel, g2, dim3(256), 0, stream, b);
       hipLaunchKernelGGL((reduce_scalar_kernel<2, Band>), dim3(1), dim3(256), 0, stream, b, nb);
@@ -427,7 +456,7 @@ int smrf_springs_band_layout(int rows_local, int cols, int64_t* h_out) {
   h_out[1] = (int64_t)L.uv;      // uv plane   (same shape)
   h_out[2] = (int64_t)L.hole;    // hole plane (rows_local + 2 rows of cols bytes)
   h_out[3] = (int64_t)L.abelow;  // cols doubles: the raster row below the band
-  h_out[4] = (int64_t)L.red;     // 1 double: the phase sum to all-reduce
+  h_out[4] = (int64_t)L.red;     // 2 doubles: the phase sums to all-reduce (PH_ATU uses both, the others the first)
   h_out[5] = (int64_t)L.total;
   return SMRF_OK;
 }

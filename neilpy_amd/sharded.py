@@ -235,7 +235,8 @@ class HipSpringsOps:
         self.uv = self.ws[lay[1]:lay[1] + n2 * 8].view(torch.float64).view(self.rows + 2, self.cols)
         self.hole = self.ws[lay[2]:lay[2] + n2].view(self.rows + 2, self.cols)
         self.abelow = self.ws[lay[3]:lay[3] + self.cols * 8].view(torch.float64)
-        self.red = self.ws[lay[4]:lay[4] + 8].view(torch.float64)
+        self.red2 = self.ws[lay[4]:lay[4] + 16].view(torch.float64)      # [|v|^2, |w|^2] of the ATU phase
+        self.red = self.red2[:1]                                          # the single sum of the other phases
 
     def _stream(self):
         import torch
@@ -295,9 +296,14 @@ def inpaint_nans_by_springs_sharded(A_band, img_rows, *, rank=None, world_size=N
     rows, float64) is filled in place.  Returns ``(istop, itn, n_unknown)`` - equal on every rank.
 
     Per LSQR iteration: rank r sends the first row of ``v`` up and the last row of ``uv`` down (one
-    row each, nearest neighbour) and three one-double all-reduces replace the three norms.  The
-    scalar recurrence runs replicated on every rank from the same reduced sums, so all ranks stop at
-    the same iteration.  Summation order differs from one device (block partials per band), so
+    row each, nearest neighbour) and TWO all-reduces replace the three norms: ``|u|^2`` alone (beta
+    must exist before ``v = S^T u - beta v``), then ``[|v|^2, |w|^2]`` as one 2-element buffer -
+    ``|dk|^2 = |w|^2 / rho^2`` with ``w`` the vector before this iteration's update, so it needs no
+    collective of its own after ``rho`` is known (lsqr.py:455-461 computes ``norm(w / rho)``; the two
+    differ by a rounding in ``ddnorm``, which only feeds the condition-number test).  Two
+    synchronisation points per iteration is LSQR's own minimum (beta, then alfa).  The scalar
+    recurrence runs replicated on every rank from the same reduced sums, so all ranks stop at the
+    same iteration.  Summation order differs from one device (block partials per band), so
     values agree to ~1e-12 and ``itn`` is normally identical (hard part 1).
     """
     import torch.distributed as dist
@@ -316,6 +322,10 @@ def inpaint_nans_by_springs_sharded(A_band, img_rows, *, rank=None, world_size=N
     def reduce():
         if multi:
             _allreduce_sum(dist, group, ops.red)
+
+    def reduce2():
+        if multi:
+            _allreduce_sum(dist, group, ops.red2)
 
     ops.begin(atol, btol, conlim, iter_lim)
     ops.phase(PH_MASK)
@@ -342,10 +352,9 @@ def inpaint_nans_by_springs_sharded(A_band, img_rows, *, rank=None, world_size=N
             if multi:
                 _shift(dist, group, rank, world_size, ops.uv[n], ops.uv[0], up=False)
             ops.phase(PH_ATU)
-            reduce()
+            reduce2()
             ops.phase(PH_ALFA_ROT)
             ops.phase(PH_XW)
-            reduce()
             ops.phase(PH_TESTS)
         istop, itn, nunk, done = ops.status()
     if nunk > 0:

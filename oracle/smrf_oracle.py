@@ -278,7 +278,7 @@ def inpaint_nans_by_springs(A, inplace=False, neighbors=4, return_info=False):
 # ----------------------------------------------------------------------------
 # inpaint_nans_by_fda (neilpy.py:1170-1216): assembled system, SciPy's own LSQR
 # ----------------------------------------------------------------------------
-def fda_system(A):
+def fda_system(A, return_rows=False):
     """(a, b, nan_list) of the least-squares problem the reference hands to LSQR.
 
     One equation per raster cell: vertical [1, -2, 1] unless in the first/last row plus horizontal
@@ -302,6 +302,8 @@ def fda_system(A):
     b = -L[:, known] * A.ravel()[known]
     Ln = L[:, nan_list]
     k = np.repeat(np.arange(m * n), np.diff(Ln.indptr))
+    if return_rows:                      # also the raster cell (flat index) every kept equation belongs to
+        return Ln[k], b[k], nan_list, k
     return Ln[k], b[k], nan_list
 
 

@@ -49,3 +49,11 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.fail("test marked gpu but no GPU is visible")
     return torch.device("cuda:0")
+
+
+def free_port():
+    """a TCP port nobody listens on right now (multi-process tests must not collide on a constant)"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]

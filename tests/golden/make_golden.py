@@ -483,6 +483,37 @@ def golden_create_dem(ref, rec, out):
     np.savez_compressed(os.path.join(out, "create_dem.npz"), **d)
 
 
+def golden_create_dem_samples(ref, out):
+    """create_dem on the sparse ISPRS samples at non-integer cellsizes: the inverse-affine index
+    arithmetic (neilpy.py:1141-1143) is delicate there - at cellsize 0.3 several hundred points sit
+    within one rounding of a cell edge.  Inputs come from samples.npz; the grids are
+    stored as int32 centi-units (every cell value is one of the points' z), INT32_MIN = empty."""
+    d, cases = {}, []
+    for name in ("samp52", "samp54", "samp71"):
+        x, y, z, _ = load_sample(name)
+        for cs, tag in ((0.3, "0p3"), (0.7, "0p7")):
+            I, t = ref.create_dem(x, y, z, cellsize=cs, bin_type="min")
+            key = "%s_cs%s" % (name, tag)
+            zc = np.where(np.isnan(I), -2 ** 31, np.round(np.nan_to_num(I) * 100.0)).astype(np.int64)
+            back = np.where(zc == -2 ** 31, np.nan, zc / 100.0)
+            assert np.array_equal(back, I, equal_nan=True)
+            d[key + "_I_centi"] = zc.astype(np.int32)
+            d[key + "_transform"] = np.array(t[:6], dtype=np.float64)
+            d[key + "_cellsize"] = np.array(cs)
+            # how many points the naive (x - west) / cellsize index would put in another column or row
+            w, n = t[2], t[5]
+            naive_c = np.floor((x - w) / cs).astype(np.int64)
+            naive_r = np.floor((n - y) / cs).astype(np.int64)
+            c, r = ~t * (x, y)
+            delicate = int(np.count_nonzero((np.floor(c).astype(np.int64) != naive_c) |
+                                            (np.floor(r).astype(np.int64) != naive_r)))
+            d[key + "_delicate_points"] = np.array(delicate)
+            cases.append(key)
+            print("create_dem", key, I.shape, "occupied", int((~np.isnan(I)).sum()), "delicate", delicate, flush=True)
+    d["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(out, "create_dem_samples.npz"), **d)
+
+
 def golden_las(ref, out):
     """LAS files written by neilpy_amd.las.write_las (formats 0-10, LAS 1.2/1.3/1.4), read back by the
     REFERENCE's read_las: header dictionary and every DataFrame column are the golden."""
@@ -569,6 +600,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "pssm":
         golden_pssm(ref, out)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "create_dem_samples":
+        golden_create_dem_samples(ref, out)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "fda":
         golden_fda(ref, Recorder(ref), out)
         return
@@ -578,6 +612,7 @@ def main():
     golden_inpaint(ref, rec, out)
     golden_fda(ref, rec, out)
     golden_create_dem(ref, rec, out)
+    golden_create_dem_samples(ref, out)
     golden_las(ref, out)
     golden_pssm(ref, out)
     anchors, published = golden_smrf(ref, rec, out)

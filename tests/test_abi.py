@@ -49,3 +49,22 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not pat.search(text), os.path.join(dirpath, f)
+
+
+def test_device_scope_refuses_mixed_devices():
+    """tensors of one call on two devices are refused before any launch (neilpy_amd/_device.py)"""
+    from neilpy_amd import SmrfHipError
+    from neilpy_amd._device import common_device
+
+    class FakeTensor:                      # what the guard looks at: torch's module, data_ptr, is_cuda, device
+        def __init__(self, device, is_cuda=True):
+            self.device, self.is_cuda = device, is_cuda
+
+        def data_ptr(self):
+            return 0
+    FakeTensor.__module__ = "torch"
+    a, b, c = FakeTensor("cuda:0"), FakeTensor("cuda:1"), FakeTensor("cpu", is_cuda=False)
+    assert common_device([1.0, None, c]) is None
+    assert common_device([a, c, "x", a]) == "cuda:0"
+    with pytest.raises(SmrfHipError, match="different devices"):
+        common_device([a, 3, b])

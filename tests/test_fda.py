@@ -114,3 +114,42 @@ def test_hip_vs_oracle_random_holes(gpu_device):
     st = neilpy_amd.last_stats["inpaint_fda"]
     assert _close_stop((st["istop"], st["itn"]), (istop, itn))
     assert np.max(np.abs(got - want)) <= RTOL * float(np.abs(want).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,frac,seed", [((9, 7), .3, 1), ((40, 33), .5, 2), ((64, 300), .2, 3), ((2, 12), .4, 4),
+                                             ((31, 2), .4, 5), ((120, 90), .85, 6)])
+def test_hip_operator_equals_explicit_system(gpu_device, shape, frac, seed):
+    """The device A v, A^T u, right-hand side and row multiplicity against the reference's explicit sparse
+    system (oracle.fda_system, neilpy.py:1180-1209): a wrong-by-one-equation stencil cannot hide inside the
+    LSQR iteration tolerance of the solve tests.  Products agree to rounding (1e-13 relative)."""
+    import ctypes as C
+    import torch
+    from neilpy_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(seed)
+    A = rng.normal(100.0, 20.0, size=shape)
+    A[rng.random(shape) < frac] = np.nan
+    a, b, nan_list, k = orc.fda_system(A, return_rows=True)
+    m, n = shape
+    v_nan = rng.normal(size=nan_list.size)
+    V = np.zeros(m * n); V[nan_list] = v_nan
+    U = rng.normal(size=m * n)                                   # one value per raster cell = per unique equation
+    want_Av = a @ v_nan                                          # per kept (duplicated) equation row
+    want_Atu = a.T @ U[k]
+    dev = lambda x, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(x)).to(gpu_device).to(dt)   # noqa: E731
+    A_d, V_d, U_d = dev(A), dev(V.reshape(shape)), dev(U.reshape(shape))
+    rhs_d, Av_d, Atu_d = (torch.zeros(shape, dtype=torch.float64, device=gpu_device) for _ in range(3))
+    cnt_d = torch.zeros(shape, dtype=torch.uint8, device=gpu_device)
+    nbytes = lib.smrf_fda_workspace_bytes(m, n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=gpu_device)
+    p = lambda t: C.c_void_p(t.data_ptr())                       # noqa: E731
+    _lib.check(lib.smrf_fda_apply_f64(p(A_d), m, n, p(V_d), p(U_d), p(rhs_d), p(cnt_d), p(Av_d), p(Atu_d), p(ws), nbytes,
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    cnt = cnt_d.cpu().numpy().ravel()
+    assert np.array_equal(cnt, np.bincount(k, minlength=m * n))  # the reference keeps a row once per NaN entry
+    rhs, Av, Atu = (t.cpu().numpy().ravel() for t in (rhs_d, Av_d, Atu_d))
+    scale = max(1.0, float(np.abs(b).max(initial=0.0)))
+    assert np.max(np.abs(rhs[k] - b), initial=0.0) <= 1e-13 * scale
+    assert np.max(np.abs(Av[k] - want_Av), initial=0.0) <= 1e-13 * max(1.0, float(np.abs(want_Av).max(initial=0.0)))
+    assert np.max(np.abs(Atu[nan_list] - want_Atu), initial=0.0) <= 1e-13 * max(1.0, float(np.abs(want_Atu).max(initial=0.0)))

@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, SAMPLES, golden, load_sample, unpack, zmin_from_centi
+from conftest import GOLDEN, SAMPLES, free_port, golden, load_sample, unpack, zmin_from_centi
 
 pytestmark = pytest.mark.gpu
 
@@ -176,6 +176,19 @@ def test_create_dem_golden(nz, tag):
         assert np.array_equal(I, want, equal_nan=True)
 
 
+CDS = golden("create_dem_samples.npz")
+
+
+@pytest.mark.parametrize("tag", [str(c) for c in CDS["cases"]])
+def test_create_dem_samples_noninteger_cellsize(nz, tag):
+    """the reference's grids for samp52/54/71 at cellsize 0.3 / 0.7 (59-301 points per case land in another cell
+    than (x - west) / cellsize would put them): bit-exact, transform equal"""
+    x, y, z, _ = load_sample(tag.split("_")[0])
+    I, t = nz.create_dem(x, y, z, cellsize=float(CDS[tag + "_cellsize"]), bin_type="min")
+    assert np.array_equal(np.array(t[:6]), CDS[tag + "_transform"])
+    assert np.array_equal(I, zmin_from_centi(CDS[tag + "_I_centi"]), equal_nan=True)
+
+
 def test_create_dem_errors(nz):
     with pytest.raises(ValueError, match="This type not supported."):
         nz.create_dem(np.array([0., 1.]), np.array([0., 1.]), np.array([0., 1.]), bin_type="mean")
@@ -315,7 +328,7 @@ def test_sharded_two_ranks_on_one_gpu(nz, tmp_path):
                          capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29611", os.path.join(ROOT, "bench.py"),
+                          "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"),
                           "--gpus", "2", "--backend", "gloo", "--share-gpu"] + common,
                          capture_output=True, text=True, timeout=600)
     assert two.returncode == 0, two.stderr[-2000:]
@@ -380,7 +393,7 @@ def test_sharded_stages_rehearsal(nz, world):
         cmd = [sys.executable, script, "--sample", "samp11"]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-               "--master-addr", "127.0.0.1", "--master-port", str(29620 + world), script, "--sample", "samp11",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script, "--sample", "samp11",
                "--backend", "gloo", "--share-gpu"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -403,7 +416,7 @@ def test_smrf_sharded_rehearsal(nz, world):
         cmd = [sys.executable, script, "--sample", "samp11"]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-               "--master-addr", "127.0.0.1", "--master-port", str(29650 + world), script, "--sample", "samp11",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script, "--sample", "samp11",
                "--backend", "gloo", "--share-gpu"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]

@@ -115,6 +115,20 @@ def test_create_dem_golden(tag):
         assert np.array_equal(I, want, equal_nan=True)
 
 
+CDS = golden("create_dem_samples.npz")
+
+
+@pytest.mark.parametrize("tag", [str(c) for c in CDS["cases"]])
+def test_create_dem_samples_noninteger_cellsize(tag):
+    """samp52/54/71 at cellsize 0.3 and 0.7: hundreds of points sit within one rounding of a cell edge
+    (counted by the generator); the inverse-affine index arithmetic must follow neilpy.py:1141-1143."""
+    x, y, z, _ = load_sample(tag.split("_")[0])
+    I, t = orc.create_dem(x, y, z, cellsize=float(CDS[tag + "_cellsize"]), bin_type="min")
+    assert np.array_equal(t[:6], CDS[tag + "_transform"])
+    assert np.array_equal(I, zmin_from_centi(CDS[tag + "_I_centi"]), equal_nan=True)
+    assert int(CDS[tag + "_delicate_points"]) >= 50
+
+
 def test_create_dem_errors():
     with pytest.raises(ValueError, match="This type not supported."):
         orc.create_dem(np.array([0., 1.]), np.array([0., 1.]), np.array([0., 1.]), bin_type="mean")

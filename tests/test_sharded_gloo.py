@@ -15,7 +15,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import ROOT
+from conftest import ROOT, free_port
 
 
 class OracleBandOps:
@@ -85,7 +85,7 @@ def _worker(rank, world, port, shape, windows, dtype_name, out_dir, budget=None)
 def test_sharded_equals_single(tmp_path, world, shape, windows, dtype, budget, exchanges):
     from oracle import smrf_oracle as orc
     from neilpy_amd.synth import synth_dem
-    port = 29500 + (os.getpid() % 2000) + world + (7 if budget == 0 else 0)
+    port = free_port()
     mp.spawn(_worker, args=(world, port, shape, windows, dtype, str(tmp_path), budget), nprocs=world, join=True)
     Z = synth_dem(shape[1], seed=31, dtype=np.float32 if dtype == "f32" else np.float64, rows=shape[0])
     want_m, want_w = orc.progressive_filter(Z, np.asarray(windows), 1, .15, return_when_dropped=True)

@@ -14,7 +14,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import ROOT, golden
+from conftest import ROOT, free_port, golden
 
 
 class NumpySpringsOps:
@@ -29,7 +29,8 @@ class NumpySpringsOps:
         self.v, self.uh, self.uv = torch.zeros(n2, dtype=torch.float64), np.zeros(n2), torch.zeros(n2, dtype=torch.float64)
         self.hole = torch.zeros(n2, dtype=torch.uint8)
         self.abelow = torch.zeros(self.cols, dtype=torch.float64)
-        self.red = torch.zeros(1, dtype=torch.float64)
+        self.red2 = torch.zeros(2, dtype=torch.float64)   # [|v|^2, |w|^2] of phase 3; the other phases use red[0]
+        self.red = self.red2[:1]
         self.sc = {}
 
     def begin(self, atol, btol, conlim, iter_lim):
@@ -88,6 +89,7 @@ class NumpySpringsOps:
             nv = np.where(h, y - s["beta"] * (s["ia"] * v[own]), v[own])
             v[own] = nv
             self.red[0] = float((nv[h] * nv[h]).sum())
+            self.red2[1] = float((self.w[own][h] ** 2).sum())       # |w|^2 rides with |v|^2 (w before this iteration's update)
         elif ph == 4:
             if s["done"]:
                 return
@@ -152,15 +154,13 @@ class NumpySpringsOps:
                 return
             h = hole[own].astype(bool)
             ws = self.w[own].copy()
-            dk = s["ir"] * ws
             self.x[own] = np.where(h, self.x[own] + s["t1"] * ws, self.x[own])
             self.w[own] = np.where(h, s["ia"] * v[own] + s["t2"] * ws, self.w[own])
-            self.red[0] = float((dk[h] ** 2).sum())
         elif ph == 9:
             if self._stopped():
                 return
             EPS = np.finfo(np.float64).eps
-            nd = sqrt(float(self.red[0]))
+            nd = sqrt((float(self.red2[1]) * s["ir"]) * s["ir"])       # |dk|^2 = |w|^2 / rho^2
             s["ddnorm"] += nd * nd
             s["itn"] += 1
             acond = s["anorm"] * sqrt(s["ddnorm"])
@@ -213,7 +213,7 @@ def test_sharded_springs_equals_reference(tmp_path, world, tag):
     g = golden("inpaint.npz")
     want = g[tag + "_out"]
     istop, itn = (int(v) for v in g[tag + "_lsqr"])
-    port = 29700 + (os.getpid() % 1500) + world
+    port = free_port()
     mp.spawn(_worker, args=(world, port, tag, str(tmp_path)), nprocs=world, join=True)
     got = np.empty_like(want)
     for r in range(world):

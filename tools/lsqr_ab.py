@@ -15,6 +15,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=8192)
 ap.add_argument("--occupancy", type=float, default=0.09)
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--pattern", default="random", choices=["random", "blocks", "objects"],
+                help="random: every cell a hole with probability 1 - occupancy; blocks: 64 x 64 blocks are holes with that "
+                     "probability (clustered, as after cutting objects out of a DTM); objects: the cells progressive_filter "
+                     "flags on the DEM (windows 1..18) are the holes, as in smrf's second inpaint")
 ap.add_argument("--libs", default="")
 a = ap.parse_args()
 import torch  # noqa: E402
@@ -25,7 +29,15 @@ lib = _lib.load()
 n = a.size
 g = torch.Generator(device="cuda").manual_seed(7)
 Z = torch.from_numpy(neilpy_amd.synth_dem(n, seed=20240).astype(np.float64)).cuda()
-Z[torch.rand((n, n), device="cuda", generator=g) >= a.occupancy] = float("nan")
+if a.pattern == "random":
+    Z[torch.rand((n, n), device="cuda", generator=g) >= a.occupancy] = float("nan")
+elif a.pattern == "blocks":
+    nb = (n + 63) // 64
+    coarse = torch.rand((nb, nb), device="cuda", generator=g) >= a.occupancy
+    Z[coarse.repeat_interleave(64, 0).repeat_interleave(64, 1)[:n, :n]] = float("nan")
+else:
+    Z[neilpy_amd.progressive_filter(Z.float(), np.arange(1, 19), 1, .15)] = float("nan")
+print("pattern %s: %.1f %% holes" % (a.pattern, 100.0 * float(torch.isnan(Z).float().mean())), flush=True)
 fns = {"cur": (lib.smrf_springs_lsqr_f64, lib.smrf_springs_workspace_bytes)}
 for path in [v for v in a.libs.split(",") if v]:
     o = C.CDLL(os.path.abspath(path))
