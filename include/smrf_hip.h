@@ -164,6 +164,23 @@ SMRF_API int smrf_grid_bin_f64(const double* d_x, const double* d_y, const doubl
 SMRF_API int smrf_grid_finalize_f64(const uint64_t* d_keys, double* d_grid, uint8_t* d_empty,
                            int64_t ncells, int is_max, void* stream);
 
+/* Sharded create_dem without replicated points (the all-to-all form; create_dem semantics of
+ * neilpy/neilpy.py:1141-1156 are unchanged).  Every rank holds 1/N of the points; each point belongs to the
+ * rank whose row band holds floor(row) of `~t * (x, y)` (h_inv = the six inverse-affine coefficients, the same
+ * rounding as smrf_grid_bin_f64); bands are sharded.band_rows(): the first rows_total % nbands bands hold one
+ * row more.  nbands <= 64.
+ *   smrf_points_band_count_f64: d_counts[nbands] <- points of this rank per destination band.
+ *   smrf_points_band_pack_f64:  points copied into d_out_{x,y,z} grouped by destination band; d_cursors[nbands]
+ *     holds each band's first output index on entry (exclusive prefix sum of the counts) and its end on return.
+ *     Order inside a band's run is arbitrary (the binning is order independent).
+ * The host exchanges the runs (counts first) with all_to_all over RCCL and bins what it receives with
+ * smrf_grid_bin_f64(row0, rows_local). */
+SMRF_API int smrf_points_band_count_f64(const double* d_x, const double* d_y, int64_t npts, const double* h_inv,
+                               int rows_total, int nbands, uint64_t* d_counts, void* stream);
+SMRF_API int smrf_points_band_pack_f64(const double* d_x, const double* d_y, const double* d_z, int64_t npts,
+                              const double* h_inv, int rows_total, int nbands, uint64_t* d_cursors,
+                              double* d_out_x, double* d_out_y, double* d_out_z, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * inpaint_nans_by_springs: matrix-free LSQR on the raster's edge planes, scipy's recurrence
  * and stopping rule (damp = 0).  d_A (rows x cols, contiguous, float64) is updated in place:

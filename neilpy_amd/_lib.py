@@ -41,6 +41,8 @@ SIGNATURES = {
     "smrf_points_extent_f64": (_i, [_p, _p, _i64, C.POINTER(_d), _p, _sz, _p]),
     "smrf_las_decode_xyz_f64": (_i, [_p, _i64, _i, C.POINTER(_d), _p, _p, _p, _p]),
     "smrf_affine_apply_f64": (_i, [_p, _p, _i64, C.POINTER(_d), _p, _p, _p]),
+    "smrf_points_band_count_f64": (_i, [_p, _p, _i64, C.POINTER(_d), _i, _i, _p, _p]),
+    "smrf_points_band_pack_f64": (_i, [_p, _p, _p, _i64, C.POINTER(_d), _i, _i, _p, _p, _p, _p, _p]),
     "smrf_grid_clear_u64": (_i, [_p, _i64, _p]),
     "smrf_grid_bin_f64": (_i, [_p, _p, _p, _i64, C.POINTER(_d), C.POINTER(_d), _p, _i, _i, _i, _i, _i, _p, _p]),
     "smrf_grid_finalize_f64": (_i, [_p, _p, _p, _i64, _i, _p]),
@@ -78,7 +80,10 @@ def load():
             "libsmrf_hip.so is not built (%s missing). Run `python -m neilpy_amd.build`; "
             "neilpy_amd has no CPU fallback." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
+    override = bool(os.environ.get("NEILPY_AMD_LIB"))
     for name, (res, args) in SIGNATURES.items():
+        if override and not hasattr(lib, name):
+            continue                 # an older build under A/B may lack newer entry points; the product library may not
         fn = getattr(lib, name)      # AttributeError if the export is missing
         fn.restype = res
         fn.argtypes = args

@@ -197,7 +197,11 @@ def _dem_edges(xd, yd, cellsize):
     ws = torch.empty(4 * 1024, dtype=torch.float64, device=xd.device)
     ext = (C.c_double * 4)()
     _lib.check(lib.smrf_points_extent_f64(_ptr(xd), _ptr(yd), npts, ext, _ptr(ws), ws.numel() * 8, _stream()))
-    xmin, xmax, ymin, ymax = (np.float64(v) for v in ext)
+    return _edges_from_extent(*(np.float64(v) for v in ext), cellsize)
+
+
+def _edges_from_extent(xmin, xmax, ymin, ymax, cellsize):
+    """neilpy.py:1117-1124: cell centres on multiples of the cellsize, one spare row / column on the far side"""
     xedges = np.arange(cellsize * np.floor(xmin / cellsize) - .5 * cellsize,
                        cellsize * np.ceil(xmax / cellsize) + 1.5 * cellsize, cellsize)
     yedges = np.arange(cellsize * np.ceil(ymax / cellsize) + .5 * cellsize,

@@ -130,6 +130,74 @@ __global__ __launch_bounds__(256) void las_decode_kernel(const uint8_t* __restri
   }
 }
 
+// ---- points -> destination row band (the all-to-all form of the sharded create_dem) -----------------
+// band of a raster row under sharded.band_rows(): the first `rem` bands hold base + 1 rows, the others base
+__device__ __forceinline__ int band_of_row(int r, int base, int rem) {
+  const int split = rem * (base + 1);
+  return r < split ? r / (base + 1) : rem + (r - split) / max(base, 1);
+}
+struct BucketArgs {
+  const double *x, *y, *z;
+  long long n;
+  double id, ie, jf;              // row = x * id + y * ie + jf (the row half of the inverse affine)
+  int rows_total, nbands, base, rem;
+};
+__device__ __forceinline__ int dest_band(const BucketArgs& a, long long i) {
+  // the same rounding as bin_kernel: a point goes to the rank whose rows it will be binned into.  Rows outside the
+  // raster (or a NaN coordinate) clamp to the nearest band, whose bin_kernel then counts the point as outside.
+  const double fr = floor(__dadd_rn(__dadd_rn(__dmul_rn(a.x[i], a.id), __dmul_rn(a.y[i], a.ie)), a.jf));
+  const int r = !(fr >= 0.0) ? 0 : (fr >= (double)a.rows_total ? a.rows_total - 1 : (int)fr);
+  return min(band_of_row(r, a.base, a.rem), a.nbands - 1);
+}
+constexpr int MAXBANDS = 64;
+
+__global__ __launch_bounds__(256) void band_count_kernel(const BucketArgs a, unsigned long long* __restrict__ counts) {
+  __shared__ unsigned int h[MAXBANDS];
+  if (threadIdx.x < MAXBANDS) h[threadIdx.x] = 0;
+  __syncthreads();
+  for (long long i0 = blockIdx.x * 256ll * 16; i0 < a.n; i0 += (long long)gridDim.x * 256 * 16)
+    for (int k = 0; k < 16; ++k) {
+      const long long i = i0 + k * 256 + threadIdx.x;
+      if (i < a.n) atomicAdd(&h[dest_band(a, i)], 1u);
+    }
+  __syncthreads();
+  if (threadIdx.x < a.nbands && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+// scatter into per-band runs of the packed SoA buffers: a block reserves its share of every band's run with one
+// atomic per band, lanes take their slot inside the share from an LDS counter (order within a run is arbitrary:
+// the min/max binning downstream is order independent)
+__global__ __launch_bounds__(256) void band_pack_kernel(const BucketArgs a, unsigned long long* __restrict__ cursors,
+                                                        double* __restrict__ ox, double* __restrict__ oy,
+                                                        double* __restrict__ oz) {
+  __shared__ unsigned int h[MAXBANDS];
+  __shared__ unsigned long long basepos[MAXBANDS];
+  for (long long i0 = blockIdx.x * 256ll * 16; i0 < a.n; i0 += (long long)gridDim.x * 256 * 16) {
+    if (threadIdx.x < MAXBANDS) h[threadIdx.x] = 0;
+    __syncthreads();
+    int dest[16];
+    unsigned int slot[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const long long i = i0 + k * 256 + threadIdx.x;
+      dest[k] = -1;
+      if (i < a.n) { dest[k] = dest_band(a, i); slot[k] = atomicAdd(&h[dest[k]], 1u); }
+    }
+    __syncthreads();
+    if (threadIdx.x < a.nbands && h[threadIdx.x])
+      basepos[threadIdx.x] = atomicAdd(&cursors[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (dest[k] < 0) continue;
+      const long long i = i0 + k * 256 + threadIdx.x;
+      const unsigned long long o = basepos[dest[k]] + slot[k];
+      ox[o] = a.x[i]; oy[o] = a.y[i]; oz[o] = a.z[i];
+    }
+    __syncthreads();
+  }
+}
+
 int nblocks(long long n, int cap) { return (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, cap)); }
 
 }  // namespace
@@ -178,6 +246,43 @@ int smrf_las_decode_xyz_f64(const uint8_t* d_records, int64_t npts, int record_l
   hipLaunchKernelGGL(las_decode_kernel, dim3(nblocks(npts, 8192)), dim3(256), 0, (hipStream_t)stream, d_records,
                      (long long)npts, record_length, h_scale_offset[0], h_scale_offset[1], h_scale_offset[2],
                      h_scale_offset[3], h_scale_offset[4], h_scale_offset[5], d_x, d_y, d_z);
+  SMRF_LAUNCH_CHECK();
+  return SMRF_OK;
+}
+
+static int bucket_args(BucketArgs& a, const double* d_x, const double* d_y, const double* d_z, int64_t npts,
+                       const double* h_inv, int rows_total, int nbands) {
+  if (npts < 0 || !h_inv || (npts > 0 && (!d_x || !d_y))) return smrf_fail(SMRF_E_ARG, "null pointer");
+  if (rows_total < 1 || nbands < 1 || nbands > MAXBANDS || nbands > rows_total)
+    return smrf_fail(SMRF_E_ARG, "bad band split: %d rows over %d bands (at most %d bands)", rows_total, nbands, MAXBANDS);
+  a.x = d_x; a.y = d_y; a.z = d_z; a.n = npts;
+  a.id = h_inv[3]; a.ie = h_inv[4]; a.jf = h_inv[5];
+  a.rows_total = rows_total; a.nbands = nbands; a.base = rows_total / nbands; a.rem = rows_total % nbands;
+  return SMRF_OK;
+}
+
+int smrf_points_band_count_f64(const double* d_x, const double* d_y, int64_t npts, const double* h_inv, int rows_total,
+                               int nbands, uint64_t* d_counts, void* stream) {
+  BucketArgs a;
+  if (int rc = bucket_args(a, d_x, d_y, nullptr, npts, h_inv, rows_total, nbands)) return rc;
+  if (!d_counts) return smrf_fail(SMRF_E_ARG, "null pointer");
+  SMRF_HIP_CHECK(hipMemsetAsync(d_counts, 0, (size_t)nbands * sizeof(uint64_t), (hipStream_t)stream));
+  if (npts == 0) return SMRF_OK;
+  hipLaunchKernelGGL(band_count_kernel, dim3(nblocks((npts + 15) / 16, 4096)), dim3(256), 0, (hipStream_t)stream, a,
+                     (unsigned long long*)d_counts);
+  SMRF_LAUNCH_CHECK();
+  return SMRF_OK;
+}
+
+int smrf_points_band_pack_f64(const double* d_x, const double* d_y, const double* d_z, int64_t npts, const double* h_inv,
+                              int rows_total, int nbands, uint64_t* d_cursors, double* d_out_x, double* d_out_y,
+                              double* d_out_z, void* stream) {
+  BucketArgs a;
+  if (int rc = bucket_args(a, d_x, d_y, d_z, npts, h_inv, rows_total, nbands)) return rc;
+  if (npts == 0) return SMRF_OK;
+  if (!d_z || !d_cursors || !d_out_x || !d_out_y || !d_out_z) return smrf_fail(SMRF_E_ARG, "null pointer");
+  hipLaunchKernelGGL(band_pack_kernel, dim3(nblocks((npts + 15) / 16, 4096)), dim3(256), 0, (hipStream_t)stream, a,
+                     (unsigned long long*)d_cursors, d_out_x, d_out_y, d_out_z);
   SMRF_LAUNCH_CHECK();
   return SMRF_OK;
 }

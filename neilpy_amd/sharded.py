@@ -10,6 +10,11 @@ take 12 exchanges instead of 50.
 Image borders use scipy's reflect rule inside the kernels, exactly as on one GPU, so the result
 is bit-identical to the single-device path (neilpy.py:1659-1680 semantics).
 
+Overlap: the rows a group's exchange sends are the band's outermost sum(2r) rows of the surface the
+previous group leaves.  That group's last dilation is therefore split: the two edge strips run first, on
+a side stream, followed by the exchange; the interior runs beside them on the main stream, which only
+waits for the exchange before the next group's first erosion.
+
 The communication uses ``torch.distributed`` point-to-point ops, so the same driver runs on
 ``nccl`` (= RCCL) with CUDA tensors and on ``gloo`` with CPU tensors; the compute is delegated
 to a ``BandOps`` object.  The product default is :class:`HipBandOps` (libsmrf_hip); the CPU tests
@@ -22,7 +27,7 @@ import numpy as np
 from . import _lib
 
 __all__ = ["band_rows", "window_groups", "HipBandOps", "progressive_filter_sharded", "HipSpringsOps",
-           "inpaint_nans_by_springs_sharded", "create_dem_band", "smrf_sharded"]
+           "inpaint_nans_by_springs_sharded", "create_dem_band", "HipPointOps", "create_dem_sharded", "smrf_sharded"]
 
 
 def band_rows(img_rows, world_size, rank):
@@ -50,19 +55,27 @@ class HipBandOps:
         import torch
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    def erode(self, src, src_row0, dst, dst_row0, dst_rows, img_rows, radius):
+    def has_nan(self, band):
+        """NaNs in this rank's rows?  (scipy's filters let the first visited footprint element decide NaN-ness; the
+        kernels follow that rule only when told to, so the driver asks once per call and all-reduces the answer)"""
+        cnt = C.c_int64(0)
+        fn = getattr(self.lib, "smrf_count_nan_" + self._sfx(band))
+        _lib.check(fn(C.c_void_p(band.data_ptr()), band.numel(), C.byref(cnt), self._stream()))
+        return cnt.value > 0
+
+    def erode(self, src, src_row0, dst, dst_row0, dst_rows, img_rows, radius, nan_aware=0):
         fn = getattr(self.lib, "smrf_disk_filter_" + self._sfx(src))
         _lib.check(fn(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), img_rows, src.shape[1], src.shape[1],
-                      src_row0, src.shape[0], dst_row0, dst_rows, int(radius), 0, 0, self.impl, self._stream()))
+                      src_row0, src.shape[0], dst_row0, dst_rows, int(radius), 0, int(nan_aware), self.impl, self._stream()))
 
     def dilate_flag(self, eroded, er_row0, er_rows, last_band, opened_band, mask, when, thr, widx, band_row0,
-                    band_nrows, img_rows, radius):
+                    band_nrows, img_rows, radius, nan_aware=0):
         fn = getattr(self.lib, "smrf_pf_dilate_flag_" + self._sfx(eroded))
         cols = eroded.shape[1]
         _lib.check(fn(C.c_void_p(eroded.data_ptr()), C.c_void_p(last_band.data_ptr()),
                       C.c_void_p(opened_band.data_ptr()), C.c_void_p(mask.data_ptr()),
                       C.c_void_p(when.data_ptr()) if when is not None else C.c_void_p(0), float(thr), int(widx),
-                      img_rows, cols, cols, er_row0, er_rows, band_row0, band_nrows, int(radius), 0, self.impl,
+                      img_rows, cols, cols, er_row0, er_rows, band_row0, band_nrows, int(radius), int(nan_aware), self.impl,
                       self._stream()))
 
 
@@ -176,16 +189,41 @@ def progressive_filter_sharded(Z_band, img_rows, windows, thresholds, *, rank=No
     cur = 0
     ext[cur][off:off + nloc].copy_(Z_band)
     st["exchanges"] = 0
-    for grp in groups:
+    # scipy's NaN rule (first visited footprint element decides) costs the kernels a read per cell: only when some
+    # band holds a NaN, as the single-device path decides with one count
+    nan_aware = 0
+    if hasattr(ops, "has_nan"):
+        nan_aware = int(bool(ops.has_nan(Z_band)))
+        if world_size > 1 and dist.is_initialized():
+            flag = torch.tensor([nan_aware], dtype=torch.int32, device=dev if dist.get_backend(group) != "gloo" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+            nan_aware = int(flag.item())
+    kw = {"nan_aware": nan_aware} if nan_aware else {}
+    # overlap (CUDA tensors): the exchange a group needs is posted on a side stream as soon as the previous group's
+    # last dilation has produced the band's edge rows, and runs beside that dilation's interior
+    side = st.get("side")
+    if side is None and Z_band.is_cuda and world_size > 1:
+        side = st["side"] = torch.cuda.Stream(device=dev)
+    M_of = [sum(2 * windows[i] for i in g) if world_size > 1 else 0 for g in groups]
+
+    def exchange(last, M):
+        lo, hi = max(0, b0 - M), min(img_rows, b1 + M)
+        _exchange(dist, group, rank, world_size,
+                  last[off:off + M], last[lo - e0:off] if rank > 0 else None,
+                  last[off + nloc - M:off + nloc], last[off + nloc:hi - e0] if rank < world_size - 1 else None)
+        st["exchanges"] += 1
+
+    posted = None                                            # event of an exchange posted ahead for the next group
+    for gi, grp in enumerate(groups):
         # rows of `last` the whole group needs beyond the band: every opening eats 2r of them
-        M = sum(2 * windows[i] for i in grp) if world_size > 1 else 0
+        M = M_of[gi]
         if M > 0:
-            last = ext[cur]
-            lo, hi = max(0, b0 - M), min(img_rows, b1 + M)
-            _exchange(dist, group, rank, world_size,
-                      last[off:off + M], last[lo - e0:off] if rank > 0 else None,
-                      last[off + nloc - M:off + nloc], last[off + nloc:hi - e0] if rank < world_size - 1 else None)
-            st["exchanges"] += 1
+            if posted is not None:
+                if posted is not True:
+                    torch.cuda.current_stream().wait_event(posted)
+                posted = None
+            else:
+                exchange(ext[cur], M)
         for i in grp:
             r = windows[i]
             last = ext[cur]
@@ -197,14 +235,43 @@ def progressive_filter_sharded(Z_band, img_rows, windows, thresholds, *, rank=No
                 M -= 2 * r
                 o0, o1 = max(0, b0 - M), min(img_rows, b1 + M)          # opening: r more rows inside (the band at the end)
             dst = ero[q0 - e0:q1 - e0]
-            ops.erode(last[lo - e0:hi - e0], lo, dst, q0, q1 - q0, img_rows, r)
+            ops.erode(last[lo - e0:hi - e0], lo, dst, q0, q1 - q0, img_rows, r, **kw)
             nxt = ext[1 - cur]
-            # margin rows are flagged too (same values the neighbour computes for them); only the band's are returned
-            ops.dilate_flag(dst, q0, q1 - q0, last[o0 - e0:o1 - e0], nxt[o0 - e0:o1 - e0], mask[o0 - e0:o1 - e0],
-                            when[o0 - e0:o1 - e0] if when is not None else None, float(thresholds[i]), i, o0, o1 - o0,
-                            img_rows, r)
+
+            def dilate(y0, y1):
+                # margin rows are flagged too (same values the neighbour computes for them); only the band's are returned
+                ops.dilate_flag(dst, q0, q1 - q0, last[y0 - e0:y1 - e0], nxt[y0 - e0:y1 - e0], mask[y0 - e0:y1 - e0],
+                                when[y0 - e0:y1 - e0] if when is not None else None, float(thresholds[i]), i, y0, y1 - y0,
+                                img_rows, r, **kw)
+            Mn = M_of[gi + 1] if (i == grp[-1] and gi + 1 < len(groups)) else 0
+            if Mn > 0 and o0 == b0 and o1 == b1 and nloc >= 2 * Mn:
+                # last window of the group: the Mn edge rows either side first, then the next group's exchange beside
+                # the interior (the neighbours need exactly those rows of the opened surface)
+                if side is not None:
+                    ready = torch.cuda.Event()
+                    ready.record()                                       # the erosion is enqueued before this point
+                    with torch.cuda.stream(side):
+                        side.wait_event(ready)
+                        dilate(b0, b0 + Mn)
+                        dilate(b1 - Mn, b1)
+                        exchange(nxt, Mn)
+                        posted = torch.cuda.Event()
+                        posted.record()
+                    if nloc > 2 * Mn:
+                        dilate(b0 + Mn, b1 - Mn)
+                else:                                                    # CPU tensors (gloo tests): same split, in order
+                    dilate(b0, b0 + Mn)
+                    dilate(b1 - Mn, b1)
+                    exchange(nxt, Mn)
+                    posted = True
+                    if nloc > 2 * Mn:
+                        dilate(b0 + Mn, b1 - Mn)
+            else:
+                dilate(o0, o1)
             if len(windows) > 1:
                 cur = 1 - cur
+    if side is not None:
+        torch.cuda.current_stream().wait_stream(side)        # nothing of this call is left running on the side stream
     return mask[off:off + nloc], (when[off:off + nloc] if when is not None else None)
 
 
@@ -388,6 +455,133 @@ def create_dem_band(xd, yd, zd, inv_affine, grid_shape, *, rank, world_size, bin
     return grid, empty, int(n_out.item())
 
 
+class HipPointOps:
+    """Point-side device operators of the sharded create_dem (libsmrf_hip, include/smrf_hip.h)."""
+
+    def __init__(self):
+        self.lib = _lib.load()
+        _lib.require_gpu()
+
+    @staticmethod
+    def _st():
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def extent(self, xd, yd):
+        """(xmin, xmax, ymin, ymax) of this rank's points; (+inf, -inf, +inf, -inf) for none"""
+        import torch
+        if xd.numel() == 0:
+            return (np.inf, -np.inf, np.inf, -np.inf)
+        ws = torch.empty(4 * 1024, dtype=torch.float64, device=xd.device)
+        ext = (C.c_double * 4)()
+        _lib.check(self.lib.smrf_points_extent_f64(C.c_void_p(xd.data_ptr()), C.c_void_p(yd.data_ptr()), xd.numel(), ext,
+                                                   C.c_void_p(ws.data_ptr()), ws.numel() * 8, self._st()))
+        return tuple(float(v) for v in ext)
+
+    def bucket(self, xd, yd, zd, inv, rows_total, nbands):
+        """points grouped by destination row band: (counts int64[nbands] on the device, x, y, z packed runs)"""
+        import torch
+        h_inv = (C.c_double * 6)(*[float(v) for v in inv])
+        p = lambda t: C.c_void_p(t.data_ptr())                  # noqa: E731
+        counts = torch.zeros(nbands, dtype=torch.int64, device=xd.device)
+        _lib.check(self.lib.smrf_points_band_count_f64(p(xd), p(yd), xd.numel(), h_inv, rows_total, nbands, p(counts), self._st()))
+        cursors = torch.cumsum(counts, 0) - counts               # exclusive prefix sum: each band's first slot
+        ox, oy, oz = torch.empty_like(xd), torch.empty_like(yd), torch.empty_like(zd)
+        _lib.check(self.lib.smrf_points_band_pack_f64(p(xd), p(yd), p(zd), xd.numel(), h_inv, rows_total, nbands, p(cursors),
+                                                      p(ox), p(oy), p(oz), self._st()))
+        return counts, ox, oy, oz
+
+    def bin_band(self, xd, yd, zd, inv, grid_shape, row0, rows_local, bin_type):
+        """(float64 band, uint8 empty mask, points outside the raster) from the points this rank received"""
+        import torch
+        ny, nx = grid_shape
+        p = lambda t: C.c_void_p(t.data_ptr())                  # noqa: E731
+        keys = torch.empty((rows_local, nx), dtype=torch.int64, device=xd.device)
+        n_out = torch.zeros(1, dtype=torch.int64, device=xd.device)
+        grid = torch.empty((rows_local, nx), dtype=torch.float64, device=xd.device)
+        empty = torch.empty((rows_local, nx), dtype=torch.uint8, device=xd.device)
+        h_inv = (C.c_double * 6)(*[float(v) for v in inv])
+        is_max = 1 if bin_type == 'max' else 0
+        _lib.check(self.lib.smrf_grid_clear_u64(p(keys), keys.numel(), self._st()))
+        _lib.check(self.lib.smrf_grid_bin_f64(p(xd), p(yd), p(zd), xd.numel(), h_inv, None, p(keys), ny, nx, row0, rows_local,
+                                              is_max, p(n_out), self._st()))
+        _lib.check(self.lib.smrf_grid_finalize_f64(p(keys), p(grid), p(empty), keys.numel(), is_max, self._st()))
+        return grid, empty, int(n_out.item())
+
+
+def _a2a(dist, group, out, inp, out_splits, in_splits):
+    """all_to_all_single; gloo stages CUDA tensors through the host (rehearsals on a one-GPU box)"""
+    if dist.get_backend(group) == "gloo" and inp.is_cuda:
+        ho = out.cpu()
+        dist.all_to_all_single(ho, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+        out.copy_(ho)
+    else:
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+
+
+def create_dem_sharded(xd, yd, zd, cellsize=1, bin_type='max', *, rank=None, world_size=None, group=None, ops=None):
+    """create_dem (neilpy/neilpy.py:1110-1166) with the POINTS sharded: every rank passes its own 1/N of the cloud
+    and gets its row band of the raster - nothing is replicated (the all-to-all form).
+
+    1. extents: local min/max (device reduction), one 4-double all-reduce(min) -> the same edges, shape and
+       transform on every rank (:1117-1124, :1141);
+    2. every point is routed to the rank whose band holds ``floor(row)`` of ``~t * (x, y)`` - bucketed on the device
+       (count, prefix sum, pack), the counts and then the three coordinate runs exchanged with ``all_to_all_single``
+       (RCCL; about 24 B per point cross the links once);
+    3. the received points are binned into the band with the same 64-bit ``atomicMin`` as on one device (:1151-1156).
+    Returns ``(band float64, empty uint8, transform, (ny, nx), (b0, b1))``.  Bit-identical to the rows
+    ``b0:b1`` of the single-device raster: min / max do not depend on the order points arrive in.
+    """
+    import torch
+    import torch.distributed as dist
+    from . import api
+    from .affine import from_origin
+    if world_size is None:
+        world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if bin_type not in ('max', 'min'):
+        raise ValueError('This type not supported.')                  # neilpy.py:1158
+    if ops is None:
+        ops = HipPointOps()
+    multi = world_size > 1
+    gloo = multi and dist.get_backend(group) == "gloo"
+    xmin, xmax, ymin, ymax = ops.extent(xd, yd)
+    if multi:
+        e = torch.tensor([xmin, ymin, -xmax, -ymax], dtype=torch.float64, device="cpu" if gloo else xd.device)
+        dist.all_reduce(e, op=dist.ReduceOp.MIN, group=group)          # a NaN coordinate anywhere makes them NaN, as np.min
+        xmin, ymin, xmax, ymax = float(e[0]), float(e[1]), -float(e[2]), -float(e[3])
+    if not np.isfinite([xmin, xmax, ymin, ymax]).all():
+        raise ValueError("zero-size or non-finite point set: the raster's extent is undefined")
+    xedges, yedges = api._edges_from_extent(np.float64(xmin), np.float64(xmax), np.float64(ymin), np.float64(ymax), cellsize)
+    nx, ny = len(xedges) - 1, len(yedges) - 1
+    t = from_origin(xedges[0], yedges[0], cellsize, cellsize)
+    inv = tuple(~t)[:6]
+    if multi and ny < world_size:
+        raise ValueError("a raster of %d rows cannot be split over %d ranks" % (ny, world_size))
+    b0, b1 = band_rows(ny, world_size, rank)
+    if multi:
+        counts, sx, sy, sz = ops.bucket(xd, yd, zd, inv, ny, world_size)
+        cnt = counts.cpu() if (gloo or not counts.is_cuda) else counts
+        got = torch.empty_like(cnt)
+        dist.all_to_all_single(got, cnt, group=group)                  # how many points every rank sends me
+        in_splits = [int(v) for v in counts.cpu().tolist()]
+        out_splits = [int(v) for v in got.cpu().tolist()]
+        n_in = sum(out_splits)
+        rx, ry, rz = (torch.empty(n_in, dtype=torch.float64, device=xd.device) for _ in range(3))
+        for dst_t, src_t in ((rx, sx), (ry, sy), (rz, sz)):
+            _a2a(dist, group, dst_t, src_t, out_splits, in_splits)
+        xd, yd, zd = rx, ry, rz
+    band, empty, n_out = ops.bin_band(xd, yd, zd, inv, (ny, nx), b0, b1 - b0, bin_type)
+    if multi:
+        o = torch.tensor([n_out], dtype=torch.int64, device="cpu" if gloo else band.device)
+        dist.all_reduce(o, op=dist.ReduceOp.SUM, group=group)
+        n_out = int(o.item())
+    if n_out > 0:
+        raise ValueError("invalid entry in coordinates array")       # np.ravel_multi_index, neilpy.py:1151
+    return band, empty, t, (ny, nx), (b0, b1)
+
+
 # ------------------------------------------------------------------------------------------
 # the whole smrf() over row bands
 # ------------------------------------------------------------------------------------------
@@ -411,19 +605,23 @@ def _all_gather_rows(dist, group, part, sizes):
 
 
 def smrf_sharded(x, y, z, cellsize=1, windows=5, slope_threshold=.15, elevation_threshold=.5, elevation_scaler=1.25,
-                 low_filter_slope=5, low_outlier_fill=False, *, rank=None, world_size=None, group=None):
+                 low_filter_slope=5, low_outlier_fill=False, *, rank=None, world_size=None, group=None,
+                 points="replicated"):
     """neilpy.smrf (neilpy/neilpy.py:1685-1808) with the raster split into row bands, one rank per GPU.
 
-    Every rank passes the FULL point set (replicated, or read by every rank from the same file).
-    Gridding, both spring inpaints and both progressive filters run on this rank's band
-    (create_dem_band, inpaint_nans_by_springs_sharded, progressive_filter_sharded).  The tail's
+    ``points="replicated"``: every rank passes the FULL point set (or reads it from the same file) and bins it
+    into its own rows (create_dem_band, no exchange).  ``points="sharded"``: every rank passes only its own part of
+    the cloud; the points are routed to the rank that owns their row with one all-to-all (create_dem_sharded) and the
+    tail classifies the rank's own points - nothing is replicated but the DTM the spline needs.
+    Both spring inpaints and both progressive filters run on this rank's band
+    (inpaint_nans_by_springs_sharded, progressive_filter_sharded).  The tail's
     bicubic spline is global along both axes, so the DTM bands are all-gathered and every rank
     solves the spline on the whole raster ("replicas only") but evaluates and tests only
     its own 1/N of the points; the point flags are all-gathered.
 
     Returns ``(dtm_band, transform, object_cells_band, is_object_point, (b0, b1))``: the rank's rows
-    ``b0:b1`` of the DTM (float64 CUDA) and of the object raster (bool CUDA), and the flags of ALL
-    points (bool CUDA, same on every rank).
+    ``b0:b1`` of the DTM (float64 CUDA) and of the object raster (bool CUDA), and the point flags (bool CUDA): of
+    ALL points, the same on every rank (replicated), or of the rank's own points (sharded).
     """
     import torch
     import torch.distributed as dist
@@ -438,16 +636,22 @@ def smrf_sharded(x, y, z, cellsize=1, windows=5, slope_threshold=.15, elevation_
     lib = _lib.load()
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)    # noqa: E731
     st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)              # noqa: E731
+    if points not in ("replicated", "sharded"):
+        raise ValueError("points must be 'replicated' or 'sharded'")
     xd, yd, zd = api._points_to_device(x, y, z)
-    xedges, yedges = api._dem_edges(xd, yd, cellsize)                              # :1117-1124, same on every rank
-    nx, ny = len(xedges) - 1, len(yedges) - 1
-    from .affine import from_origin
-    t = from_origin(xedges[0], yedges[0], cellsize, cellsize)
-    b0, b1 = band_rows(ny, world_size, rank)
-    band, empty, n_out = create_dem_band(xd, yd, zd, tuple(~t)[:6], (ny, nx), rank=rank, world_size=world_size,
-                                         bin_type='min')                           # :1741
-    if n_out > 0:
-        raise ValueError("invalid entry in coordinates array")
+    if points == "sharded":
+        band, empty, t, (ny, nx), (b0, b1) = create_dem_sharded(xd, yd, zd, cellsize, 'min', rank=rank,
+                                                                world_size=world_size, group=group)   # :1741
+    else:
+        xedges, yedges = api._dem_edges(xd, yd, cellsize)                          # :1117-1124, same on every rank
+        nx, ny = len(xedges) - 1, len(yedges) - 1
+        from .affine import from_origin
+        t = from_origin(xedges[0], yedges[0], cellsize, cellsize)
+        b0, b1 = band_rows(ny, world_size, rank)
+        band, empty, n_out = create_dem_band(xd, yd, zd, tuple(~t)[:6], (ny, nx), rank=rank, world_size=world_size,
+                                             bin_type='min')                       # :1741
+        if n_out > 0:
+            raise ValueError("invalid entry in coordinates array")
     stats = {"inpaint1": inpaint_nans_by_springs_sharded(band, ny, rank=rank, world_size=world_size, group=group)}
     neg = torch.empty_like(band)
     _lib.check(lib.smrf_negate_f64(p(band), p(neg), band.numel(), st()))
@@ -468,6 +672,13 @@ def smrf_sharded(x, y, z, cellsize=1, windows=5, slope_threshold=.15, elevation_
     sizes = [band_rows(ny, world_size, k)[1] - band_rows(ny, world_size, k)[0] for k in range(world_size)]
     Zpro = _all_gather_rows(dist, group, band, sizes)
     npts = xd.numel()
+    if points == "sharded":                                  # every rank classifies its own points, nothing to gather
+        if npts:
+            flags = api._classify_points_device(Zpro, t, cellsize, xd, yd, zd, elevation_threshold, elevation_scaler)[2]
+        else:
+            flags = torch.empty(0, dtype=torch.uint8, device=xd.device)
+        api.last_stats["sharded"] = stats
+        return band, t, object_cells.bool(), flags.bool(), (b0, b1)
     psz = [band_rows(npts, world_size, k)[1] - band_rows(npts, world_size, k)[0] for k in range(world_size)]
     p0, p1 = band_rows(npts, world_size, rank)
     if p1 > p0:

@@ -112,3 +112,92 @@ def test_smrf_small_and_error_paths(nz, orc):
         nz.smrf(np.array([0.0, 9.0]), np.array([0.0, 0.4]), np.array([1.0, 2.0]), cellsize=1)
     with pytest.raises(NotImplementedError):
         nz.create_dem(x, y, z, use_binned_statistic=True)
+
+
+@pytest.mark.parametrize("with_nan", [False, True])
+@pytest.mark.parametrize("world,shape,windows,budget", [(3, (330, 300), [1, 2, 3, 5, 4, 8], 24), (2, (200, 131), [2, 6, 1], None),
+                                                        (4, (512, 260), [1, 2, 3, 4, 5, 6, 7, 8, 9, 10], 40)])
+def test_sharded_driver_bands_on_one_gpu(nz, orc, gpu_device, world, shape, windows, budget, with_nan):
+    """neilpy_amd.sharded's row-band driver with the HIP band operators, every rank run in turn on this GPU: the grouped
+    halo exchange, the edge-first split of a group's last dilation (side stream) and - ``with_nan`` - scipy's NaN rule
+    across band borders (the sharded path used to ignore NaNs).  A neighbour's message is replaced by the
+    same rows of the surface entering the group, computed on the whole raster.  Masks and when_dropped bit-exact
+    against the oracle."""
+    import torch
+    from neilpy_amd import sharded
+    rng = np.random.default_rng(world * 100 + shape[0])
+    Z = nz.synth_dem(shape[1], seed=9, rows=shape[0]).astype(np.float32)
+    if with_nan:
+        Z[rng.random(shape) < .02] = np.nan
+        Z[shape[0] // world - 1, 5:40] = np.nan                       # a run of NaNs on a band's last row
+    win = np.asarray(windows)
+    thr = .15 * (win * 1)
+    want_m, want_w = orc.progressive_filter(Z, win, 1, .15, return_when_dropped=True)
+    Zd = torch.from_numpy(Z).to(gpu_device)
+    min_band = min(sharded.band_rows(shape[0], world, k)[1] - sharded.band_rows(shape[0], world, k)[0] for k in range(world))
+    groups = sharded.window_groups([int(w) for w in win], min_band, budget)
+    entering, last = [], Zd
+    for grp in groups:
+        entering.append(last)
+        for i in grp:
+            last = nz.opening(last, radius=int(win[i]))
+    real = sharded._exchange
+    try:
+        for k in range(world):
+            b0, b1 = sharded.band_rows(shape[0], world, k)
+            calls = []
+
+            def fake_exchange(dist, group, rank, world_size, send_up, recv_up, send_down, recv_down):
+                src = entering[len(calls)]
+                calls.append(send_up.shape[0])
+                # what this rank sends must be what the whole-raster surface holds in those rows (NaNs compare equal)
+                assert torch.equal(torch.nan_to_num(send_up, nan=-7.0), torch.nan_to_num(src[b0:b0 + send_up.shape[0]], nan=-7.0))
+                assert torch.equal(torch.nan_to_num(send_down, nan=-7.0), torch.nan_to_num(src[b1 - send_down.shape[0]:b1], nan=-7.0))
+                if recv_up is not None:
+                    recv_up.copy_(src[b0 - recv_up.shape[0]:b0])
+                if recv_down is not None:
+                    recv_down.copy_(src[b1:b1 + recv_down.shape[0]])
+            sharded._exchange = fake_exchange
+            ops = sharded.HipBandOps()
+            if with_nan:
+                ops.has_nan = lambda band: True                           # the all-reduced flag of a real run
+            mask, when = sharded.progressive_filter_sharded(Zd[b0:b1].contiguous(), shape[0], win, thr, rank=k, world_size=world,
+                                                            ops=ops, return_when_dropped=True, halo_budget=budget)
+            torch.cuda.synchronize()
+            assert calls == [sum(2 * int(win[i]) for i in g) for g in groups]
+            assert np.array_equal(mask.cpu().numpy().astype(bool), want_m[b0:b1]), (k, "mask")
+            assert np.array_equal(when.cpu().numpy(), want_w[b0:b1]), (k, "when")
+    finally:
+        sharded._exchange = real
+
+
+@pytest.mark.parametrize("nbands", [1, 3, 8, 64])
+def test_point_bucket_kernels_route_every_point_to_its_band(nz, gpu_device, nbands):
+    """smrf_points_band_count / _pack (the all-to-all gridding of sharded.create_dem_sharded): the packed runs are a
+    permutation of the cloud, every point sits in the run of the band that owns floor(row), and binning run k
+    into band k gives the rows of the single-device raster bit for bit."""
+    import torch
+    from neilpy_amd import sharded
+    x, y, z = nz.synth_points(300_000, 700.0, seed=5)
+    x[:1000] = np.round(x[:1000]) + .5                       # points exactly on cell edges
+    y[1000:2000] = np.round(y[1000:2000]) - .5
+    I, t = nz.create_dem(x, y, z, cellsize=1, bin_type="min")
+    ny, nx = I.shape
+    inv = tuple(~t)[:6]
+    xd, yd, zd = (torch.from_numpy(v).to(gpu_device) for v in (x, y, z))
+    ops = sharded.HipPointOps()
+    counts, px, py, pz = ops.bucket(xd, yd, zd, inv, ny, nbands)
+    counts = counts.cpu().numpy()
+    assert counts.sum() == len(x)
+    key = lambda a, b, c: np.sort(a * 1e6 + b * 1e-3 + c)    # noqa: E731
+    assert np.array_equal(key(px.cpu().numpy(), py.cpu().numpy(), pz.cpu().numpy()), key(x, y, z))
+    row = np.floor((px.cpu().numpy() * inv[3] + py.cpu().numpy() * inv[4]) + inv[5])      # the device's order of operations
+    start = 0
+    for k in range(nbands):
+        b0, b1 = sharded.band_rows(ny, nbands, k)
+        run = slice(start, start + int(counts[k]))
+        assert np.all((row[run] >= b0) & (row[run] < b1)), k
+        band, empty, n_out = ops.bin_band(px[run].contiguous(), py[run].contiguous(), pz[run].contiguous(), inv, (ny, nx),
+                                          b0, b1 - b0, "min")
+        assert n_out == 0 and np.array_equal(band.cpu().numpy(), I[b0:b1], equal_nan=True), k
+        start += int(counts[k])

@@ -402,8 +402,8 @@ def test_sharded_stages_rehearsal(nz, world):
     assert j["inpaint_max_abs_err"] < 1e-7, j
 
 
-@pytest.mark.parametrize("world", [1, 3])
-def test_smrf_sharded_rehearsal(nz, world):
+@pytest.mark.parametrize("world,points", [(1, "replicated"), (3, "replicated"), (3, "sharded")])
+def test_smrf_sharded_rehearsal(nz, world, points):
     """the whole smrf() over row bands (neilpy_amd.sharded.smrf_sharded) on 1 and 3 ranks sharing this
     GPU (gloo-staged halos and gathers) against samp11's goldens: object raster and point flags bit-exact,
     both LSQR solves stop at the reference's iteration, DTM within 1e-7"""
@@ -417,7 +417,7 @@ def test_smrf_sharded_rehearsal(nz, world):
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script, "--sample", "samp11",
-               "--backend", "gloo", "--share-gpu"]
+               "--backend", "gloo", "--share-gpu", "--points", points]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])

@@ -46,6 +46,13 @@ band, empty, n_out = sharded.create_dem_band(xd, yd, zd, tuple(~t)[:6], shape, r
 zmin = np.where(gold["Zmin_centi"] == -2 ** 31, np.nan, gold["Zmin_centi"] / 100.0)
 ok_dem = bool(np.array_equal(band.cpu().numpy(), zmin[b0:b1], equal_nan=True)) and n_out == 0
 
+# the same raster from SHARDED points: this rank passes only its 1/N of the cloud (all-to-all by destination band)
+p0, p1 = sharded.band_rows(len(x), world, rank)
+band2, empty2, t2, shape2, (c0, c1) = sharded.create_dem_sharded(xd[p0:p1].contiguous(), yd[p0:p1].contiguous(),
+                                                                  zd[p0:p1].contiguous(), 1, "min", rank=rank, world_size=world)
+ok_dem = ok_dem and shape2 == shape and (c0, c1) == (b0, b1) and tuple(t2)[:6] == tuple(t)[:6] and \
+    bool(torch.equal(torch.nan_to_num(band2, nan=-1.0), torch.nan_to_num(band, nan=-1.0))) and bool(torch.equal(empty2, empty))
+
 istop, itn, nunk = sharded.inpaint_nans_by_springs_sharded(band, shape[0], rank=rank, world_size=world)
 ok_lsqr = (istop, itn) == tuple(int(v) for v in gold["lsqr1"])
 if "inpaint1" in gold.files:

@@ -15,6 +15,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--sample", default="samp11")
 ap.add_argument("--backend", default="nccl")
 ap.add_argument("--share-gpu", action="store_true")
+ap.add_argument("--points", default="replicated", choices=["replicated", "sharded"],
+                help="sharded: every rank passes only its slice of the cloud (all-to-all gridding, local point flags)")
 a = ap.parse_args()
 
 import torch  # noqa: E402
@@ -35,13 +37,14 @@ gold = np.load(os.path.join(G, "smrf_%s.npz" % a.sample))
 meta = json.load(open(os.path.join(G, "meta.json")))
 x, y, z = (smp[a.sample + "_" + k] / 100.0 for k in "xyz")
 kw = dict(meta["smrf_kwargs"])
-dtm, t, obj, pts, (b0, b1) = sharded.smrf_sharded(x, y, z, **kw)
+p0, p1 = (0, len(x)) if a.points == "replicated" else sharded.band_rows(len(x), world, rank)
+dtm, t, obj, pts, (b0, b1) = sharded.smrf_sharded(x[p0:p1], y[p0:p1], z[p0:p1], points=a.points, **kw)
 shape = tuple(int(v) for v in gold["shape"])
 nbits = shape[0] * shape[1]
 want_obj = np.unpackbits(gold["object_cells_bits"])[:nbits].reshape(shape).astype(bool)
 want_pts = np.unpackbits(gold["is_object_point_bits"])[:len(x)].astype(bool)
 ok_obj = bool(np.array_equal(obj.cpu().numpy(), want_obj[b0:b1]))
-ok_pts = bool(np.array_equal(pts.cpu().numpy(), want_pts))
+ok_pts = bool(np.array_equal(pts.cpu().numpy(), want_pts[p0:p1]))
 ok_t = tuple(float(v) for v in tuple(t)[:6]) == tuple(float(v) for v in gold["transform"])
 if "Zpro" in gold.files:
     err = float(np.abs(dtm.cpu().numpy() - gold["Zpro"][b0:b1]).max())
@@ -61,10 +64,15 @@ if world > 1:
 res, e = res.cpu(), e.cpu()
 if "Zpro" not in gold.files:
     e = torch.tensor([abs(float(e[0]) - float(gold["Zpro_sum"][0]))])
+npts_obj = torch.tensor([float(pts.sum().item())], dtype=torch.float64)
+if world > 1 and a.points == "sharded":
+    if a.backend == "nccl":
+        npts_obj = npts_obj.to(dev)
+    dist.all_reduce(npts_obj, op=dist.ReduceOp.SUM)
 if rank == 0:
-    print(json.dumps(dict(sample=a.sample, world=world, object_cells_ok=bool(res[0]), is_object_point_ok=bool(res[1]),
+    print(json.dumps(dict(sample=a.sample, world=world, points=a.points, object_cells_ok=bool(res[0]), is_object_point_ok=bool(res[1]),
                           transform_ok=bool(res[2]), lsqr_itn_ok=bool(res[3]),
-                          dtm_err=float(e[0]), object_points=int(pts.sum().item()))), flush=True)
+                          dtm_err=float(e[0]), object_points=int(npts_obj.item()))), flush=True)
 if world > 1:
     dist.barrier()
     dist.destroy_process_group()
