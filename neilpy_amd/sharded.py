@@ -10,8 +10,8 @@ take 12 exchanges instead of 50.
 Image borders use scipy's reflect rule inside the kernels, exactly as on one GPU, so the result
 is bit-identical to the single-device path (neilpy.py:1659-1680 semantics).
 
-Overlap: the rows a group's exchange sends are the band's outermost sum(2r) rows of the surface the
-previous group leaves.  That group's last dilation is therefore split: the two edge strips run first, on
+Overlap (``overlap=True``): the rows a group's exchange sends are the band's outermost sum(2r) rows of the
+surface the previous group leaves.  That group's last dilation is split: the two edge strips run first, on
 a side stream, followed by the exchange; the interior runs beside them on the main stream, which only
 waits for the exchange before the next group's first erosion.
 
@@ -133,7 +133,7 @@ def window_groups(windows, min_band_rows, budget=None):
 
 
 def progressive_filter_sharded(Z_band, img_rows, windows, thresholds, *, rank=None, world_size=None, group=None,
-                               ops=None, return_when_dropped=False, state=None, halo_budget=None):
+                               ops=None, return_when_dropped=False, state=None, halo_budget=None, overlap=False):
     """progressive_filter on this rank's row band ``Z_band`` (rows ``band_rows(img_rows, W, rank)``).
 
     Returns the band's ``(mask, when_dropped | None)`` as uint8 tensors on ``Z_band``'s device.
@@ -142,7 +142,10 @@ def progressive_filter_sharded(Z_band, img_rows, windows, thresholds, *, rank=No
     ``state`` (a dict) keeps the extended buffers between calls so a benchmark loop does not
     re-allocate (and reports ``state["exchanges"]``).  ``halo_budget``: rows of halo a group of
     consecutive windows may share in one exchange (see :func:`window_groups`; 0 = one exchange
-    per window).
+    per window).  ``overlap=True`` splits every group's last dilation edge-first and posts the next group's exchange
+    on a side stream beside the interior (module docstring).  Off by default: on a 2048-row band the two edge
+    strips cost about 160 us per group, more than an exchange of up to about 0.45 ms returns
+    (tools/band_compute.py, gpurun_out/r02/band_compute.log); it pays on slower links only.
     """
     import torch
     import torch.distributed as dist
@@ -243,7 +246,7 @@ def progressive_filter_sharded(Z_band, img_rows, windows, thresholds, *, rank=No
                 ops.dilate_flag(dst, q0, q1 - q0, last[y0 - e0:y1 - e0], nxt[y0 - e0:y1 - e0], mask[y0 - e0:y1 - e0],
                                 when[y0 - e0:y1 - e0] if when is not None else None, float(thresholds[i]), i, y0, y1 - y0,
                                 img_rows, r, **kw)
-            Mn = M_of[gi + 1] if (i == grp[-1] and gi + 1 < len(groups)) else 0
+            Mn = M_of[gi + 1] if (overlap and i == grp[-1] and gi + 1 < len(groups)) else 0
             if Mn > 0 and o0 == b0 and o1 == b1 and nloc >= 2 * Mn:
                 # last window of the group: the Mn edge rows either side first, then the next group's exchange beside
                 # the interior (the neighbours need exactly those rows of the opened surface)

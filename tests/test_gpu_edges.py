@@ -162,7 +162,8 @@ def test_sharded_driver_bands_on_one_gpu(nz, orc, gpu_device, world, shape, wind
             if with_nan:
                 ops.has_nan = lambda band: True                           # the all-reduced flag of a real run
             mask, when = sharded.progressive_filter_sharded(Zd[b0:b1].contiguous(), shape[0], win, thr, rank=k, world_size=world,
-                                                            ops=ops, return_when_dropped=True, halo_budget=budget)
+                                                            ops=ops, return_when_dropped=True, halo_budget=budget,
+                                                            overlap=(k % 2 == 0))       # both forms of the driver
             torch.cuda.synchronize()
             assert calls == [sum(2 * int(win[i]) for i in g) for g in groups]
             assert np.array_equal(mask.cpu().numpy().astype(bool), want_m[b0:b1]), (k, "mask")

@@ -69,7 +69,7 @@ def _worker(rank, world, port, shape, windows, dtype_name, out_dir, budget=None)
         for _ in range(2):                       # second call reuses the buffers
             mask, when = sharded.progressive_filter_sharded(band, shape[0], win, thr, rank=rank, world_size=world,
                                                             ops=OracleBandOps(), return_when_dropped=True, state=state,
-                                                            halo_budget=budget)
+                                                            halo_budget=budget, overlap=(len(windows) % 2 == 0))
         np.savez(os.path.join(out_dir, "r%d.npz" % rank), mask=mask.numpy(), when=when.numpy(), b0=b0, b1=b1,
                  exchanges=state["exchanges"])
     finally:
