@@ -8,13 +8,6 @@
 
 #include "smrf_common.h"
 
-#ifdef SMRF_STAMPS
-static unsigned long long* g_stamp_buf = nullptr;   // device buffer of 16 counters (diagnostic build)
-extern "C" __attribute__((visibility("default"))) void smrf_debug_set_stamp_buffer(unsigned long long* d_buf) {
-  g_stamp_buf = d_buf;
-}
-#endif
-
 namespace {
 
 // ------------------------------------------------------------------------------------------
@@ -88,7 +81,7 @@ __global__ __launch_bounds__(256) void count_nan_kernel(const T* __restrict__ p,
 
 template <typename T> struct RingFn;
 template <> struct RingFn<float> {
-  static int call(const DiskArgs<float>& a, bool d, hipStream_t s) {
+  static int call(const DiskArgs<float>& a, int d, hipStream_t s) {
     switch (a.radius % SMRF_RING_PARTS) {
       case 0: return smrf_ring_f32_p0(a, d, s);
       case 1: return smrf_ring_f32_p1(a, d, s);
@@ -102,7 +95,7 @@ template <> struct RingFn<float> {
   }
 };
 template <> struct RingFn<double> {
-  static int call(const DiskArgs<double>& a, bool d, hipStream_t s) {
+  static int call(const DiskArgs<double>& a, int d, hipStream_t s) {
     switch (a.radius % SMRF_RING_PARTS) {
       case 0: return smrf_ring_f64_p0(a, d, s);
       case 1: return smrf_ring_f64_p1(a, d, s);
@@ -158,10 +151,7 @@ int disk_filter(DiskArgs<T> a, bool dilate, int impl, hipStream_t stream) {
     if (a.radius > SMRF_RING_MAX_RADIUS)
       return smrf_fail(SMRF_E_UNSUPPORTED, "ring kernels cover radius <= %d (got %d)", SMRF_RING_MAX_RADIUS, a.radius);
     a.seg = smrf_env_int("SMRF_RING_SEG", 0);   // 0: the launcher sizes segments from its occupancy
-#ifdef SMRF_STAMPS
-    a.dbg = g_stamp_buf;
-#endif
-    return RingFn<T>::call(a, dilate, stream);
+    return RingFn<T>::call(a, dilate ? SMRF_RING_DILATE : SMRF_RING_ERODE, stream);
   }
   if (impl != SMRF_IMPL_DIRECT) return smrf_fail(SMRF_E_ARG, "unknown impl %d", impl);
   dim3 grid((a.cols + 63) / 64, (a.out_rows + 3) / 4);
@@ -236,10 +226,22 @@ int progressive_filter_api(const T* Z, int rows, int cols, const int32_t* window
     nan_aware = c > 0;
   }
   const T* last = Z;
+  // small disks: opening + flag in ONE launch, the eroded surface never leaves the CU (morph_fused.h; 10 instead of
+  // 22 B/cell in fp32).  Not for rasters with NaNs (scipy's NaN rule lives in the two-pass kernels only).
+  const bool fuse_ok = !nan_aware && (impl == SMRF_IMPL_AUTO || impl == SMRF_IMPL_RING) && smrf_env_int("SMRF_FUSED", 1) != 0;
   for (int i = 0; i < nwin; ++i) {
     const int r = windows[i];
-    if (int rc = disk_filter_api<T>(last, E, rows, cols, cols, 0, rows, 0, rows, r, 0, nan_aware, impl, stream_)) return rc;
     T* opened = O[i & 1];
+    if (fuse_ok && r >= 1 && r <= SMRF_FUSED_MAX_RADIUS) {
+      DiskArgs<T> a{};
+      a.in = last; a.last = last; a.out = opened; a.mask = mask; a.when = when; a.thr = thr[i]; a.widx = i;
+      a.img_rows = rows; a.cols = cols; a.ld = cols; a.in_row0 = 0; a.in_rows = rows; a.out_row0 = 0; a.out_rows = rows;
+      a.radius = r; a.nan_aware = 0; a.seg = smrf_env_int("SMRF_RING_SEG", 0);
+      if (int rc = RingFn<T>::call(a, SMRF_RING_FUSED_OPEN, stream)) return rc;
+      if (nwin > 1) last = opened;
+      continue;
+    }
+    if (int rc = disk_filter_api<T>(last, E, rows, cols, cols, 0, rows, 0, rows, r, 0, nan_aware, impl, stream_)) return rc;
     if (int rc = dilate_flag_api<T>(E, last, opened, mask, when, thr[i], i, rows, cols, cols, 0, rows, 0, rows, r,
                                     nan_aware, impl, stream_))
       return rc;

@@ -264,29 +264,6 @@ constexpr int ring_np() {
 }
 #define SMRF_RING_NP(T, R) ring_np<T, R, SMRF_RING_TW_OF(T, R)>()
 
-// Diagnostic build only (-DSMRF_STAMPS): per-phase wave-cycle sums, written to a buffer of their own
-// (never read by the kernel, never part of an output).  Not compiled into the product library.
-#ifdef SMRF_STAMPS
-#define SMRF_STAMP_DECL unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define SMRF_STAMP(i)                                              \
-  do {                                                             \
-    __builtin_amdgcn_sched_barrier(0);                             \
-    const unsigned long long st_t1 = __builtin_amdgcn_s_memtime(); \
-    __builtin_amdgcn_s_waitcnt(0xC07F);                            \
-    st_acc[i] += st_t1 - st_t0;                                    \
-    st_t0 = st_t1;                                                 \
-    __builtin_amdgcn_sched_barrier(0);                             \
-  } while (0)
-#define SMRF_STAMP_FLUSH                                                                         \
-  if ((threadIdx.x & 63) == 0 && a.dbg != nullptr) {                                             \
-    for (int i = 0; i < 10; ++i) atomicAdd(&a.dbg[i], st_acc[i]);                                 \
-    atomicAdd(&a.dbg[15], 1ull);                                                                  \
-  }
-#else
-#define SMRF_STAMP_DECL
-#define SMRF_STAMP(i)
-#define SMRF_STAMP_FLUSH
-#endif
 
 // reflect-folded local row index of consecutive global rows without a division per row
 struct RowFold {
@@ -306,14 +283,208 @@ struct RowFold {
   }
 };
 
+// The table build and the consume phase of one batch (NP row pairs whose level-0 cells are staged and visible to the
+// whole workgroup): base level, higher levels (a barrier after each), then per pair the window lookups and the ring
+// update.  Shared by the single-pass kernels and by both stages of the fused opening (morph_fused.h).
+//   v[p][i]  the lane's own staged cells of pair p (cell OFF + tid + i * TW), NPB of them per pair are built
+//   acc      the ring (2R partial output rows), outv <- the 2 * NP rows this batch completes
+//   OFF = 0, NPB = NPOS: every staged cell (TW + 2R per row).  OFF = R, NPB = 1: only the TW cells under the lanes
+//   (the fused opening's second stage, whose level 0 holds the first stage's TW eroded columns)
+template <typename T, int R, bool DIL, int TW, int NP, int NPB, int OFF, typename Sync>
+__device__ __forceinline__ void ring_build_consume(typename Vec2<T>::type* const L, const int par, const int tid,
+                                                   const bool has_last,
+                                                   typename Vec2<T>::type (&v)[NP][RingCfg<T, R, TW, NP>::NPOS],
+                                                   T (&acc)[2 * R], T (&outv)[2 * NP], Sync&& phase_sync) {
+  using C = RingCfg<T, R, TW, NP>;
+  using S = typename C::S;
+  using T2 = typename Vec2<T>::type;
+  constexpr int J = S::J, K = S::K, WP = C::WP, G = C::G, NG = C::NG, NLEV = C::NLEV, D = C::D;
+  constexpr int KR1 = S::kidx(R - 1);                   // width index of dy = +-(R-1)
+  constexpr int JB = C::JB, SB = C::slot_of(JB);
+  const unsigned lds_q = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(L + tid + R);
+  // the build phases end in barriers the whole workgroup waits at: let a wave in them win the issue arbitration
+  // against the SIMD's other wave (which is usually consuming); measured -3...-5.5 % at every radius >= 8
+  __builtin_amdgcn_s_setprio(SMRF_RING_BUILD_PRIO);
+  // (2) base level JB from level 0: 2^JB - 1 independent reads per cell.  All reads of the
+  //     batch are issued first (asm ds_read_b64: hipcc would fuse them into half-rate
+  //     ds_read2_b64), then one wait, then the min/max and the writes.
+  constexpr int NA = (1 << JB) - 1;
+  const unsigned lds_l = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(L + tid + OFF);
+#pragma unroll
+  for (int i = 0; i < NPB; ++i) {
+    if (i < NPB - 1 || has_last) {
+      T2 na[NP][NA];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const unsigned ad = lds_l + ((p * NLEV + par) * WP + i * TW) * (unsigned)sizeof(T2);
+        [&]<int... Kk>(std::integer_sequence<int, Kk...>) {
+          ((na[p][Kk] = lds_read2<(Kk + 1) * (int)sizeof(T2)>(ad, T())), ...);
+        }(std::make_integer_sequence<int, NA>{});
+      }
+      lds_wait<0>();
+      const int pos = tid + OFF + i * TW;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const T2* n = na[p];
+        T2 m = v[p][i];
+        if constexpr (JB == 1) { m.x = op2<DIL>(m.x, n[0].x); m.y = op2<DIL>(m.y, n[0].y); }
+        if constexpr (JB >= 2) {
+          m.x = op3<DIL>(m.x, n[0].x, n[1].x); m.y = op3<DIL>(m.y, n[0].y, n[1].y);
+          m.x = op2<DIL>(m.x, n[2].x); m.y = op2<DIL>(m.y, n[2].y);
+        }
+        if constexpr (JB == 3) {
+          m.x = op3<DIL>(m.x, n[3].x, n[4].x); m.y = op3<DIL>(m.y, n[3].y, n[4].y);
+          m.x = op3<DIL>(m.x, n[5].x, n[6].x); m.y = op3<DIL>(m.y, n[5].y, n[6].y);
+        }
+        v[p][i] = m;
+        L[(p * NLEV + SB) * WP + pos] = m;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  phase_sync();
+  // (3) levels JB+1 .. J from the base level: cells pos + k * 2^JB, k < 2^(J-JB).  One job per (cell position,
+  //     row pair): NB independent reads, then the min/max chain and the stores.  Jobs are software-pipelined two
+  //     deep (the next job's reads are issued before this job's wait), within the 15 LDS operations a wave may have
+  //     outstanding; round 1 drained every job on its own and spent 14 % of the R = 50 wave time here.
+  if constexpr (J > JB) {
+    constexpr int NB = (1 << (J - JB)) - 1;
+    constexpr int NBUF = (2 * NB <= 15 && NP > 1) ? 2 : 1;
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+      if (i < NPB - 1 || has_last) {
+        const int pos = tid + OFF + i * TW;
+        T2 nb[NBUF][NB];
+        auto issue_job = [&]<int P>(std::integral_constant<int, P>) {
+          const unsigned ad = lds_l + ((P * NLEV + SB) * WP + i * TW) * (unsigned)sizeof(T2);
+          [&]<int... Kk>(std::integer_sequence<int, Kk...>) {
+            ((nb[P % NBUF][Kk] = lds_read2<((Kk + 1) << JB) * (int)sizeof(T2)>(ad, T())), ...);
+          }(std::make_integer_sequence<int, NB>{});
+        };
+        auto finish_job = [&]<int P>(std::integral_constant<int, P>) {
+          const T2* n = nb[P % NBUF];
+          T2 m = v[P][i];
+          [&]<int... JJ>(std::integer_sequence<int, JJ...>) {
+            (([&] {
+               constexpr int j = JB + 1 + JJ;            // level being completed
+               constexpr int k0 = 1 << (j - 1 - JB);     // new cells k0 .. 2*k0 - 1
+               if constexpr (k0 == 1) { m.x = op2<DIL>(m.x, n[0].x); m.y = op2<DIL>(m.y, n[0].y); }
+               else {
+#pragma unroll
+                 for (int k = k0; k < 2 * k0; k += 2) {
+                   m.x = op3<DIL>(m.x, n[k - 1].x, n[k].x); m.y = op3<DIL>(m.y, n[k - 1].y, n[k].y);
+                 }
+               }
+               if constexpr (C::stored(j)) {
+                 constexpr int sj = C::slot_of(j);
+                 L[(P * NLEV + sj) * WP + pos] = m;
+               }
+             }()), ...);
+          }(std::make_integer_sequence<int, J - JB>{});
+        };
+        if constexpr (NBUF == 2) issue_job(std::integral_constant<int, 0>{});
+        [&]<int... P>(std::integer_sequence<int, P...>) {
+          (([&] {
+             if constexpr (NBUF == 2) {
+               // the stores of job P-1 were issued before these reads: in-order completion covers them too
+               if constexpr (P + 1 < NP) issue_job(std::integral_constant<int, P + 1>{});
+               lds_wait<(P + 1 < NP ? NB : 0)>();
+             } else {
+               issue_job(std::integral_constant<int, P>{});
+               lds_wait<0>();
+             }
+             finish_job(std::integral_constant<int, P>{});
+             __builtin_amdgcn_sched_barrier(0);
+           }()), ...);
+        }(std::make_integer_sequence<int, NP>{});
+      }
+    }
+    phase_sync();
+  }
+
+  __builtin_amdgcn_s_setprio(0);
+  // (4) consume: window lookups + ring update, pair by pair
+  {
+  T2 own[NP];                                            // the lane's own cells (level 0)
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+    own[p] = lds_read2<0>(lds_q + (p * NLEV + par) * WP * (unsigned)sizeof(T2), T());
+  lds_wait<0>();
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const unsigned q = lds_q + p * NLEV * WP * (unsigned)sizeof(T2);   // this lane's cell, level 0
+    T ra[K], rb[K];                                      // window results of row A / row B per width
+    T2 ta[D][G], tb[D][G];                              // D lookup groups in flight
+    auto issue = [&]<int GI>(std::integral_constant<int, GI>) {
+      [&]<int... I>(std::integer_sequence<int, I...>) {
+        (([&] {
+           constexpr int k = 1 + GI * G + I;
+           if constexpr (k < K) {
+             constexpr int w = S::wk(k);
+             constexpr int j = clog2(2 * w + 1);
+             constexpr int base = C::slot_of(j) * WP;
+             static_assert(C::stored(j), "lookup level not built");
+             ta[GI % D][I] = lds_read2<(base - w) * (int)sizeof(T2)>(q, T());
+             tb[GI % D][I] = lds_read2<(base + w - (1 << j) + 1) * (int)sizeof(T2)>(q, T());
+           }
+         }()), ...);
+      }(std::make_integer_sequence<int, G>{});
+    };
+    auto reduce = [&]<int GI>(std::integral_constant<int, GI>) {
+      [&]<int... I>(std::integer_sequence<int, I...>) {
+        (([&] {
+           constexpr int k = 1 + GI * G + I;
+           if constexpr (k < K) {
+             ra[k] = op2<DIL>(ta[GI % D][I].x, tb[GI % D][I].x);
+             rb[k] = op2<DIL>(ta[GI % D][I].y, tb[GI % D][I].y);
+           }
+         }()), ...);
+      }(std::make_integer_sequence<int, G>{});
+    };
+    auto slots = [&]<int GI>(std::integral_constant<int, GI>) {   // ring slots released by group GI
+      [&]<int... Sl>(std::integer_sequence<int, Sl...>) {
+        (([&] {
+           if constexpr (C::slot_group(Sl) == GI) {
+             constexpr int ka = C::kA(Sl), kb = C::kB(Sl);   // forced compile-time: static registers
+             acc[Sl] = op3<DIL>(acc[Sl + 2], ra[ka], rb[kb]);
+           }
+         }()), ...);
+      }(std::make_integer_sequence<int, (2 * R - 2 > 0 ? 2 * R - 2 : 0)>{});
+    };
+
+    [&]<int... GI>(std::integer_sequence<int, GI...>) {   // prologue: the first D-1 groups
+      (([&] { if constexpr (GI < NG) issue(std::integral_constant<int, GI>{}); }()), ...);
+    }(std::make_integer_sequence<int, D - 1>{});
+    ra[0] = own[p].x;
+    rb[0] = own[p].y;
+    // the two rows this pair completes (before their slots are overwritten)
+    outv[2 * p] = op2<DIL>(acc[0], ra[0]);
+    [&]<int... GI>(std::integer_sequence<int, GI...>) {
+      (([&] {
+         if constexpr (GI + D - 1 < NG) issue(std::integral_constant<int, GI + D - 1>{});
+         lds_wait<2 * C::inflight_after(GI)>();           // reads of the groups issued after group GI
+         reduce(std::integral_constant<int, GI>{});
+         if constexpr (GI == 0) {
+           if constexpr (R >= 2) outv[2 * p + 1] = op3<DIL>(acc[1], ra[KR1], rb[0]);
+         }
+         slots(std::integral_constant<int, GI>{});
+       }()), ...);
+    }(std::make_integer_sequence<int, NG>{});
+    if constexpr (R == 1) outv[2 * p + 1] = op3<DIL>(acc[1], ra[KR1], rb[0]);
+    slots(std::integral_constant<int, NG>{});           // second half, all widths are in registers
+    acc[2 * R - 2] = op2<DIL>(ra[0], rb[KR1]);
+    acc[2 * R - 1] = rb[0];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  }
+}
+
 template <typename T, int R, bool DIL, int TW, int NP>
 __global__ __launch_bounds__(TW, (SMRF_OCC_OVERRIDE(TW > 256 ? (RingCfg<T, R, TW, NP>::OCC * 256 / TW < 1 ? 1 : RingCfg<T, R, TW, NP>::OCC * 256 / TW) : RingCfg<T, R, TW, NP>::OCC)))
 void ring_kernel(const DiskArgs<T> a) {
   using C = RingCfg<T, R, TW, NP>;
-  using S = typename C::S;
   using T2 = typename Vec2<T>::type;
-  constexpr int J = S::J, K = S::K, WP = C::WP, G = C::G, NG = C::NG, ROWS = C::ROWS, NLEV = C::NLEV, D = C::D;
-  constexpr int KR1 = S::kidx(R - 1);                   // width index of dy = +-(R-1)
+  constexpr int WP = C::WP, ROWS = C::ROWS, NLEV = C::NLEV;
   extern __shared__ __attribute__((aligned(16))) unsigned char smrf_lds[];
   T2* const L = reinterpret_cast<T2*>(smrf_lds);         // [NP][NLEV][WP] of {row A, row B}
 
@@ -350,7 +521,6 @@ void ring_kernel(const DiskArgs<T> a) {
   };
   const bool flag = a.mask != nullptr;
   const int xc = x < a.cols ? x : a.cols - 1;
-  const unsigned lds_q = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(L + tid + R);
 
   // ring: between pairs, slot s holds the partial result of output row (next input row) - R + s
   T acc[2 * R];
@@ -445,8 +615,6 @@ void ring_kernel(const DiskArgs<T> a) {
   };
 
   prefetch();
-  SMRF_STAMP_DECL
-  constexpr int JB = C::JB, SB = C::slot_of(JB);
   int par = 0;                                           // which level-0 copy this batch uses
   for (int yy0 = ystart; yy0 < ye + R; yy0 += ROWS, par ^= 1) {
     // (1) stage the prefetched rows into this batch's level-0 copy.  The other copy may still be
@@ -461,202 +629,13 @@ void ring_kernel(const DiskArgs<T> a) {
         if (i < NPOS - 1 || has_last) L[(p * NLEV + par) * WP + tid + i * TW] = v[p][i];
       }
     }
-    SMRF_STAMP(0);                                         // wait for prefetched rows + LDS stage writes
     phase_sync();
-    SMRF_STAMP(1);                                         // barrier 1
     if (yy0 > ystart) epilogue(yy0 - ROWS);
-    SMRF_STAMP(2);                                         // epilogue stores
     if (yy0 + ROWS < ye + R) prefetch();
     load_last(yy0);
-    SMRF_STAMP(3);                                         // issue of next loads
 
-    // the build phases end in barriers the whole workgroup waits at: let a wave in them win the issue arbitration
-    // against the SIMD's other wave (which is usually consuming); measured -3...-5.5 % at every radius >= 8
-    __builtin_amdgcn_s_setprio(SMRF_RING_BUILD_PRIO);
-#ifndef SMRF_EXP_NOBUILD
-    // (2) base level JB from level 0: 2^JB - 1 independent reads per cell.  All reads of the
-    //     batch are issued first (asm ds_read_b64: hipcc would fuse them into half-rate
-    //     ds_read2_b64), then one wait, then the min/max and the writes.
-    constexpr int NA = (1 << JB) - 1;
-    const unsigned lds_l = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(L + tid);
-#pragma unroll
-    for (int i = 0; i < NPOS; ++i) {
-      if (i < NPOS - 1 || has_last) {
-        T2 na[NP][NA];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          const unsigned ad = lds_l + ((p * NLEV + par) * WP + i * TW) * (unsigned)sizeof(T2);
-          [&]<int... Kk>(std::integer_sequence<int, Kk...>) {
-            ((na[p][Kk] = lds_read2<(Kk + 1) * (int)sizeof(T2)>(ad, T())), ...);
-          }(std::make_integer_sequence<int, NA>{});
-        }
-        lds_wait<0>();
-        const int pos = tid + i * TW;
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          const T2* n = na[p];
-          T2 m = v[p][i];
-          if constexpr (JB == 1) { m.x = op2<DIL>(m.x, n[0].x); m.y = op2<DIL>(m.y, n[0].y); }
-          if constexpr (JB >= 2) {
-            m.x = op3<DIL>(m.x, n[0].x, n[1].x); m.y = op3<DIL>(m.y, n[0].y, n[1].y);
-            m.x = op2<DIL>(m.x, n[2].x); m.y = op2<DIL>(m.y, n[2].y);
-          }
-          if constexpr (JB == 3) {
-            m.x = op3<DIL>(m.x, n[3].x, n[4].x); m.y = op3<DIL>(m.y, n[3].y, n[4].y);
-            m.x = op3<DIL>(m.x, n[5].x, n[6].x); m.y = op3<DIL>(m.y, n[5].y, n[6].y);
-          }
-          v[p][i] = m;
-          L[(p * NLEV + SB) * WP + pos] = m;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    SMRF_STAMP(4);                                         // base level
-    phase_sync();
-    SMRF_STAMP(5);                                         // barrier 2
-    // (3) levels JB+1 .. J from the base level: cells pos + k * 2^JB, k < 2^(J-JB).  One job per (cell position,
-    //     row pair): NB independent reads, then the min/max chain and the stores.  Jobs are software-pipelined two
-    //     deep (the next job's reads are issued before this job's wait), within the 15 LDS operations a wave may have
-    //     outstanding; round 1 drained every job on its own and spent 14 % of the R = 50 wave time here.
-    if constexpr (J > JB) {
-      constexpr int NB = (1 << (J - JB)) - 1;
-      constexpr int NBUF = (2 * NB <= 15 && NP > 1) ? 2 : 1;
-#pragma unroll
-      for (int i = 0; i < NPOS; ++i) {
-        if (i < NPOS - 1 || has_last) {
-          const int pos = tid + i * TW;
-          T2 nb[NBUF][NB];
-          auto issue_job = [&]<int P>(std::integral_constant<int, P>) {
-            const unsigned ad = lds_l + ((P * NLEV + SB) * WP + i * TW) * (unsigned)sizeof(T2);
-            [&]<int... Kk>(std::integer_sequence<int, Kk...>) {
-              ((nb[P % NBUF][Kk] = lds_read2<((Kk + 1) << JB) * (int)sizeof(T2)>(ad, T())), ...);
-            }(std::make_integer_sequence<int, NB>{});
-          };
-          auto finish_job = [&]<int P>(std::integral_constant<int, P>) {
-            const T2* n = nb[P % NBUF];
-            T2 m = v[P][i];
-            [&]<int... JJ>(std::integer_sequence<int, JJ...>) {
-              (([&] {
-                 constexpr int j = JB + 1 + JJ;            // level being completed
-                 constexpr int k0 = 1 << (j - 1 - JB);     // new cells k0 .. 2*k0 - 1
-                 if constexpr (k0 == 1) { m.x = op2<DIL>(m.x, n[0].x); m.y = op2<DIL>(m.y, n[0].y); }
-                 else {
-#pragma unroll
-                   for (int k = k0; k < 2 * k0; k += 2) {
-                     m.x = op3<DIL>(m.x, n[k - 1].x, n[k].x); m.y = op3<DIL>(m.y, n[k - 1].y, n[k].y);
-                   }
-                 }
-                 if constexpr (C::stored(j)) {
-                   constexpr int sj = C::slot_of(j);
-                   L[(P * NLEV + sj) * WP + pos] = m;
-                 }
-               }()), ...);
-            }(std::make_integer_sequence<int, J - JB>{});
-          };
-          if constexpr (NBUF == 2) issue_job(std::integral_constant<int, 0>{});
-          [&]<int... P>(std::integer_sequence<int, P...>) {
-            (([&] {
-               if constexpr (NBUF == 2) {
-                 // the stores of job P-1 were issued before these reads: in-order completion covers them too
-                 if constexpr (P + 1 < NP) issue_job(std::integral_constant<int, P + 1>{});
-                 lds_wait<(P + 1 < NP ? NB : 0)>();
-               } else {
-                 issue_job(std::integral_constant<int, P>{});
-                 lds_wait<0>();
-               }
-               finish_job(std::integral_constant<int, P>{});
-               __builtin_amdgcn_sched_barrier(0);
-             }()), ...);
-          }(std::make_integer_sequence<int, NP>{});
-        }
-      }
-      SMRF_STAMP(6);                                       // higher levels
-      phase_sync();
-      SMRF_STAMP(7);                                       // barrier 3
-    }
-
-#endif  // SMRF_EXP_NOBUILD
-    __builtin_amdgcn_s_setprio(0);
-#ifdef SMRF_EXP_NOCONSUME
-    if (a.seg < 0)   // never true: keeps the consume code (and its registers) in the kernel, skips it at run time
-#endif
-    // (4) consume: window lookups + ring update, pair by pair
-    {
-    T2 own[NP];                                            // the lane's own cells (level 0)
-#pragma unroll
-    for (int p = 0; p < NP; ++p)
-      own[p] = lds_read2<0>(lds_q + (p * NLEV + par) * WP * (unsigned)sizeof(T2), T());
-    lds_wait<0>();
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const unsigned q = lds_q + p * NLEV * WP * (unsigned)sizeof(T2);   // this lane's cell, level 0
-      T ra[K], rb[K];                                      // window results of row A / row B per width
-      T2 ta[D][G], tb[D][G];                              // D lookup groups in flight
-      auto issue = [&]<int GI>(std::integral_constant<int, GI>) {
-        [&]<int... I>(std::integer_sequence<int, I...>) {
-          (([&] {
-             constexpr int k = 1 + GI * G + I;
-             if constexpr (k < K) {
-               constexpr int w = S::wk(k);
-               constexpr int j = clog2(2 * w + 1);
-               constexpr int base = C::slot_of(j) * WP;
-               static_assert(C::stored(j), "lookup level not built");
-               ta[GI % D][I] = lds_read2<(base - w) * (int)sizeof(T2)>(q, T());
-               tb[GI % D][I] = lds_read2<(base + w - (1 << j) + 1) * (int)sizeof(T2)>(q, T());
-             }
-           }()), ...);
-        }(std::make_integer_sequence<int, G>{});
-      };
-      auto reduce = [&]<int GI>(std::integral_constant<int, GI>) {
-        [&]<int... I>(std::integer_sequence<int, I...>) {
-          (([&] {
-             constexpr int k = 1 + GI * G + I;
-             if constexpr (k < K) {
-               ra[k] = op2<DIL>(ta[GI % D][I].x, tb[GI % D][I].x);
-               rb[k] = op2<DIL>(ta[GI % D][I].y, tb[GI % D][I].y);
-             }
-           }()), ...);
-        }(std::make_integer_sequence<int, G>{});
-      };
-      auto slots = [&]<int GI>(std::integral_constant<int, GI>) {   // ring slots released by group GI
-        [&]<int... Sl>(std::integer_sequence<int, Sl...>) {
-          (([&] {
-             if constexpr (C::slot_group(Sl) == GI) {
-               constexpr int ka = C::kA(Sl), kb = C::kB(Sl);   // forced compile-time: static registers
-               acc[Sl] = op3<DIL>(acc[Sl + 2], ra[ka], rb[kb]);
-             }
-           }()), ...);
-        }(std::make_integer_sequence<int, (2 * R - 2 > 0 ? 2 * R - 2 : 0)>{});
-      };
-
-      [&]<int... GI>(std::integer_sequence<int, GI...>) {   // prologue: the first D-1 groups
-        (([&] { if constexpr (GI < NG) issue(std::integral_constant<int, GI>{}); }()), ...);
-      }(std::make_integer_sequence<int, D - 1>{});
-      ra[0] = own[p].x;
-      rb[0] = own[p].y;
-      // the two rows this pair completes (before their slots are overwritten)
-      outv[2 * p] = op2<DIL>(acc[0], ra[0]);
-      [&]<int... GI>(std::integer_sequence<int, GI...>) {
-        (([&] {
-           if constexpr (GI + D - 1 < NG) issue(std::integral_constant<int, GI + D - 1>{});
-           lds_wait<2 * C::inflight_after(GI)>();           // reads of the groups issued after group GI
-           reduce(std::integral_constant<int, GI>{});
-           if constexpr (GI == 0) {
-             if constexpr (R >= 2) outv[2 * p + 1] = op3<DIL>(acc[1], ra[KR1], rb[0]);
-           }
-           slots(std::integral_constant<int, GI>{});
-         }()), ...);
-      }(std::make_integer_sequence<int, NG>{});
-      if constexpr (R == 1) outv[2 * p + 1] = op3<DIL>(acc[1], ra[KR1], rb[0]);
-      slots(std::integral_constant<int, NG>{});           // second half, all widths are in registers
-      acc[2 * R - 2] = op2<DIL>(ra[0], rb[KR1]);
-      acc[2 * R - 1] = rb[0];
-      __builtin_amdgcn_sched_barrier(0);
-      SMRF_STAMP(8);                                       // lookups + ring update of one pair
-    }
-    }
+    ring_build_consume<T, R, DIL, TW, NP, NPOS, 0>(L, par, tid, has_last, v, acc, outv, phase_sync);
   }
-  SMRF_STAMP_FLUSH
   {
     const int nb = (ye + R - ystart + ROWS - 1) / ROWS;
     epilogue(ystart + (nb - 1) * ROWS);
@@ -674,7 +653,7 @@ int ring_launch(const DiskArgs<T>& a_in, hipStream_t stream) {
   int dev = 0;
   SMRF_HIP_CHECK(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64) return smrf_fail(SMRF_E_UNSUPPORTED, "device index %d out of range", dev);
-  int& resident = resident_of[dev];
+  int resident = __atomic_load_n(&resident_of[dev], __ATOMIC_ACQUIRE);   // host threads may launch one radius at once
   if (resident == 0) {
     if (C::LDS_BYTES > 48 * 1024)
       SMRF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -683,6 +662,7 @@ int ring_launch(const DiskArgs<T>& a_in, hipStream_t stream) {
     SMRF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), TW,
                                                               C::LDS_BYTES));
     resident = std::max(1, nb);
+    __atomic_store_n(&resident_of[dev], resident, __ATOMIC_RELEASE);
     if (smrf_env_int("SMRF_RING_DEBUG", 0))
       fprintf(stderr, "smrf ring: R=%d %s%s NP=%d G=%d LDS=%zu built for %d waves/SIMD, %d workgroups/CU resident\n", R,
               sizeof(T) == 4 ? "f32" : "f64", DIL ? " dilate" : " erode", NP, C::G, C::LDS_BYTES, C::OCC, resident);

@@ -5,7 +5,7 @@
 #undef SMRF_RING_TW            // tuning builds with 512-column strips: fp32 only (LDS offsets of the fp64 table exceed 16 bits)
 #define SMRF_RING_TW 256
 #endif
-#include "morph_ring.h"
+#include "morph_fused.h"
 
 #ifndef PART
 #error "compile with -DPART=0..7"
@@ -22,22 +22,26 @@ using elem_t = float;
 
 namespace {
 template <int R>
-int launch_r(const DiskArgs<elem_t>& a, bool dilate, hipStream_t s) {
-  return dilate ? smrf::ring_launch<elem_t, R, true>(a, s) : smrf::ring_launch<elem_t, R, false>(a, s);
+int launch_r(const DiskArgs<elem_t>& a, int mode, hipStream_t s) {
+  if (mode == SMRF_RING_FUSED_OPEN) {
+    if constexpr (R <= SMRF_FUSED_MAX_RADIUS) return smrf::fused_launch<elem_t, R>(a, s);
+    else return smrf_fail(SMRF_E_UNSUPPORTED, "the fused opening covers radius <= %d (got %d)", SMRF_FUSED_MAX_RADIUS, R);
+  }
+  return mode == SMRF_RING_DILATE ? smrf::ring_launch<elem_t, R, true>(a, s) : smrf::ring_launch<elem_t, R, false>(a, s);
 }
 }  // namespace
 
-int SMRF_RING_FN(const DiskArgs<elem_t>& a, bool dilate, hipStream_t s) {
+int SMRF_RING_FN(const DiskArgs<elem_t>& a, int mode, hipStream_t s) {
   constexpr int P = (PART == 0) ? SMRF_RING_PARTS : PART;   // radii P, P+8, ..., P+56
   switch (a.radius) {
-    case P: return launch_r<P>(a, dilate, s);
-    case P + 8: return launch_r<P + 8>(a, dilate, s);
-    case P + 16: return launch_r<P + 16>(a, dilate, s);
-    case P + 24: return launch_r<P + 24>(a, dilate, s);
-    case P + 32: return launch_r<P + 32>(a, dilate, s);
-    case P + 40: return launch_r<P + 40>(a, dilate, s);
-    case P + 48: return launch_r<P + 48>(a, dilate, s);
-    case P + 56: return launch_r<P + 56>(a, dilate, s);
+    case P: return launch_r<P>(a, mode, s);
+    case P + 8: return launch_r<P + 8>(a, mode, s);
+    case P + 16: return launch_r<P + 16>(a, mode, s);
+    case P + 24: return launch_r<P + 24>(a, mode, s);
+    case P + 32: return launch_r<P + 32>(a, mode, s);
+    case P + 40: return launch_r<P + 40>(a, mode, s);
+    case P + 48: return launch_r<P + 48>(a, mode, s);
+    case P + 56: return launch_r<P + 56>(a, mode, s);
     default: return smrf_fail(SMRF_E_ARG, "ring dispatcher %d got radius %d", PART, a.radius);
   }
 }

@@ -58,14 +58,18 @@ struct DiskArgs {
   int radius;
   int nan_aware;
   int seg;            // output rows per workgroup (ring kernels)
-  unsigned long long* dbg;   // diagnostic builds only (SMRF_STAMPS): 8 counters, else NULL
 };
 
-// ring-kernel dispatchers, one per (dtype, radius % SMRF_RING_PARTS); defined in ring_part.hip
+// ring-kernel dispatchers, one per (dtype, radius % SMRF_RING_PARTS); defined in ring_part.hip.
+// mode: erosion, dilation (+ flag step when mask != NULL), or the fused opening + flag of morph_fused.h (in = last)
+enum { SMRF_RING_ERODE = 0, SMRF_RING_DILATE = 1, SMRF_RING_FUSED_OPEN = 2 };
+#ifndef SMRF_FUSED_MAX_RADIUS
+#define SMRF_FUSED_MAX_RADIUS 8
+#endif
 #define SMRF_RING_PARTS 8
 #define SMRF_RING_DECL(P)                                                                     \
-  SMRF_HIDDEN int smrf_ring_f32_p##P(const DiskArgs<float>&, bool dilate, hipStream_t);       \
-  SMRF_HIDDEN int smrf_ring_f64_p##P(const DiskArgs<double>&, bool dilate, hipStream_t);
+  SMRF_HIDDEN int smrf_ring_f32_p##P(const DiskArgs<float>&, int mode, hipStream_t);          \
+  SMRF_HIDDEN int smrf_ring_f64_p##P(const DiskArgs<double>&, int mode, hipStream_t);
 SMRF_RING_DECL(0) SMRF_RING_DECL(1) SMRF_RING_DECL(2) SMRF_RING_DECL(3)
 SMRF_RING_DECL(4) SMRF_RING_DECL(5) SMRF_RING_DECL(6) SMRF_RING_DECL(7)
 #undef SMRF_RING_DECL

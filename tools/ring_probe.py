@@ -49,16 +49,7 @@ def main():
         e0.record(); out.copy_(Z); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
     print("copy  %.3f ms  %.0f GB/s" % (min(ts), n * n * 2 * elem / min(ts) / 1e6), flush=True)
-    stamp_lib = None
-    for path in [v for v in a.libs.split(",") if v]:
-        if "stamps" in path:
-            stamp_lib = C.CDLL(os.path.abspath(path))
-            sbuf = torch.zeros(16, dtype=torch.int64, device="cuda")
-            stamp_lib.smrf_debug_set_stamp_buffer.argtypes = [C.c_void_p]
-            stamp_lib.smrf_debug_set_stamp_buffer(C.c_void_p(sbuf.data_ptr()))
     for r in [int(v) for v in a.radii.split(",")]:
-        if stamp_lib is not None:
-            sbuf.zero_()
         ts = {k: [] for k in fns}
         for i in range(a.reps + 1):
             for name, fn in fns.items():           # interleaved rounds: same box, same clocks
@@ -79,13 +70,6 @@ def main():
             t = float(np.median(ts[name]))
             print("r=%2d %-8s %.3f ms  %.0f GB/s (2 plane passes)  %.1f Gcell/s" %
                   (r, name, t, n * n * 2 * elem / t / 1e6, n * n / t / 1e6), flush=True)
-        if stamp_lib is not None:
-            v = sbuf.cpu().numpy().astype(np.float64)
-            tot = v[:10].sum()
-            names = ["wait-pf+stage", "bar1", "epilogue", "issue-loads", "baseLvl", "bar2", "hiLvls", "bar3", "consume", "-"]
-            print("      stamps (share of wave cycles, %d waves): " % int(v[15]) +
-                  "  ".join("%s %.1f%%" % (nm, 100 * x / tot) for nm, x in zip(names, v[:9])) +
-                  "  | cycles/wave %.3g" % (tot / max(v[15], 1)), flush=True)
 
 
 if __name__ == "__main__":
