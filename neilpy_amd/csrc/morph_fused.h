@@ -14,7 +14,7 @@
 //     erosion by the symmetric disk, and an "eroded row -3" computed this way IS what scipy's reflect hands the
 //     dilation there (eroded[fold(-3)]).  A segment therefore only starts 2R rows earlier than a plain ring pass.
 //   - Both stages are ring_build_consume of morph_ring.h (tables, lookups, register ring), min for the first,
-//     max for the second; six barriers per batch instead of three.
+//     max for the second, one after the other: six barriers per batch instead of three.
 // The NaN rule of scipy's filters is not implemented here: the host only takes this path for NaN-free rasters.
 #pragma once
 #include "morph_ring.h"
@@ -25,10 +25,13 @@
 
 namespace smrf {
 
-// row pairs per batch of the fused kernel (both stages): 2 keeps two tables per workgroup small enough for four
-// resident workgroups per CU at every fused radius
+// Row pairs per batch of the fused kernel (both stages), per radius.  More pairs spread the six barriers of a batch
+// over more rows, fewer pairs halve the two tables' LDS and let 8 instead of 4 (3 at R = 8) workgroups share a CU;
+// measured per radius on the 16384^2 benchmark DEM (gpurun_out/r02/fused3_per_radius_f32.log).  Running the two
+// stages' phases side by side under three barriers per batch (second stage one batch behind) was measured too:
+// no faster at any radius, slower at most (fused2_per_radius_f32.log), so the stages simply follow each other.
 template <typename T>
-constexpr int fused_np() { return sizeof(T) == 4 ? 2 : 1; }
+constexpr int fused_np(int r) { return sizeof(T) == 4 ? ((r == 2 || r == 3 || r == 8) ? 1 : 2) : 1; }
 
 template <typename T, int R, int TW, int NP>
 __global__ __launch_bounds__(TW, 4)
@@ -151,9 +154,11 @@ void fused_open_kernel(const DiskArgs<T> a) {
 #pragma unroll
       for (int i = 0; i < NPOS; ++i) {
         v[p][i] = pf[p][i];
-        if (i < NPOS - 1 || has_last) LE[(p * NLEV + par) * WP + tid + i * TW] = v[p][i];
+        if (i < NPOS - 1 || has_last)
+          lds_write2((unsigned)(size_t)(__attribute__((address_space(3))) void*)(LE + (p * NLEV + par) * WP + tid + i * TW), v[p][i]);
       }
     }
+    lds_wait<0>();                                         // asm stores: complete them before the barrier
     phase_sync();
     if (yy0 > ystart) epilogue(yy0 - ROWS);                // stores older than the loads issued next
     if (yy0 + ROWS < ye + 2 * R) prefetch();
@@ -164,8 +169,9 @@ void fused_open_kernel(const DiskArgs<T> a) {
     for (int p = 0; p < NP; ++p) {
       v[p][0].x = outvE[2 * p];
       v[p][0].y = outvE[2 * p + 1];
-      LD[(p * NLEV + par) * WP + tid + R] = v[p][0];
+      lds_write2((unsigned)(size_t)(__attribute__((address_space(3))) void*)(LD + (p * NLEV + par) * WP + tid + R), v[p][0]);
     }
+    lds_wait<0>();
     phase_sync();
     ring_build_consume<T, R, true, TW, NP, 1, R>(LD, par, tid, true, v, accD, outvD, phase_sync);
   }
@@ -178,7 +184,7 @@ void fused_open_kernel(const DiskArgs<T> a) {
 template <typename T, int R>
 int fused_launch(const DiskArgs<T>& a_in, hipStream_t stream) {
   constexpr int TW = 256;
-  constexpr int NP = fused_np<T>();
+  constexpr int NP = fused_np<T>(R);
   using C = RingCfg<T, R, TW, NP>;
   constexpr size_t LDS = 2 * C::LDS_BYTES;
   auto kern = fused_open_kernel<T, R, TW, NP>;
