@@ -14,6 +14,9 @@
  *   smrf_points_extent_f64,
  *   smrf_grid_*               create_dem(), neilpy/neilpy.py:1110-1166 (pandas groupby min/max
  *                             at :1151-1156, affine index arithmetic at :1141-1143)
+ *   smrf_points_band_count_f64, smrf_points_band_pack_f64
+ *                             the same index arithmetic (:1141-1143) used to route points to the rank that owns
+ *                             their raster row when the cloud is sharded over GPUs (no counterpart in the reference)
  *   smrf_springs_lsqr_f64     inpaint_nans_by_springs(), neilpy/neilpy.py:1227-1271, whose
  *                             solve is scipy.sparse.linalg.lsqr (:1264)
  *   smrf_fda_lsqr_f64         inpaint_nans_by_fda(), neilpy/neilpy.py:1170-1216
