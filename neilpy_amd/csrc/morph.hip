@@ -232,8 +232,7 @@ int progressive_filter_api(const T* Z, int rows, int cols, const int32_t* window
   for (int i = 0; i < nwin; ++i) {
     const int r = windows[i];
     T* opened = O[i & 1];
-    // fp64 tables are twice as large: the fused kernel stops paying at R = 7 there (fused2_per_radius_f64.log)
-    if (fuse_ok && r >= 1 && r <= (sizeof(T) == 4 ? SMRF_FUSED_MAX_RADIUS : std::min(6, SMRF_FUSED_MAX_RADIUS))) {
+    if (fuse_ok && r >= 1 && r <= smrf_fused_max_radius((int)sizeof(T))) {   // fp64: R <= 6 (fused2_per_radius_f64.log)
       DiskArgs<T> a{};
       a.in = last; a.last = last; a.out = opened; a.mask = mask; a.when = when; a.thr = thr[i]; a.widx = i;
       a.img_rows = rows; a.cols = cols; a.ld = cols; a.in_row0 = 0; a.in_rows = rows; a.out_row0 = 0; a.out_rows = rows;

@@ -53,6 +53,11 @@
 #ifndef SMRF_RING_G
 #define SMRF_RING_G(ringregs) ((ringregs) > 132 ? 3 : (ringregs) > 100 ? 2 : 4)
 #endif
+// widths that may be looked up with three reads of the level below instead of building the top table level for them
+// (RingCfg::DROP_TOP); per radius, measured (gpurun_out/r02/ring_top3.log)
+#ifndef SMRF_RING_TOP3
+#define SMRF_RING_TOP3(T, R) ring_tuned_top3<T>(R)
+#endif
 // tuning builds (-DSMRF_RING_NO_TUNE): most row pairs per batch the chooser ring_np() may pick
 // (fp32; fp64 cells are twice as large: half) for every radius; product builds read ring_tune.inc
 #ifndef SMRF_RING_NP_MAX
@@ -197,7 +202,20 @@ template <typename T, int R, int TW, int NP>
 struct RingCfg {
   using S = DiskShape<R>;
   static constexpr int E = sizeof(T) / 4;
-  static constexpr int J = S::J;
+  // Highest table level.  The widest widths of a disk whose 2R + 1 just passes a power of two are the only users of
+  // level S::J (R = 32: one width of 30); when there are at most SMRF_RING_TOP3 of them, that level is not built and
+  // they are looked up with THREE reads of the level below (min3: the same instruction count per row) - one table
+  // level less in LDS and 2^(J-JB-1) fewer reads per cell in the higher-level build.
+  static constexpr int n_top() {
+    int n = 0;
+    for (int k = 1; k < S::K; ++k)
+      if (clog2(2 * S::wk(k) + 1) == S::J) ++n;
+    return n;
+  }
+  static constexpr bool DROP_TOP = S::J >= 3 && n_top() <= SMRF_RING_TOP3(T, R) && 2 * R + 1 <= 3 * (1 << (S::J - 1));
+  static constexpr int J = DROP_TOP ? S::J - 1 : S::J;
+  static constexpr int lev(int w) { const int j = clog2(2 * w + 1); return j > J ? J : j; }   // level a width is read at
+  static constexpr int nreads(int w) { return clog2(2 * w + 1) > J ? 3 : 2; }
   static constexpr int W = TW + 2 * R;                   // staged cells per row
   static constexpr int PAD = 1 << J;                     // furthest build read is < 2^J cells ahead
   static constexpr int WP = ((W + PAD + 3) / 4) * 4;     // pitch of one table level (cells)
@@ -210,7 +228,7 @@ struct RingCfg {
   static constexpr bool used(int j) {
     if (j == 0) return true;
     for (int k = 1; k < S::K; ++k)
-      if (clog2(2 * S::wk(k) + 1) == j) return true;
+      if (lev(S::wk(k)) == j) return true;
     return false;
   }
   static constexpr int jmin() {                          // lowest level >= 1 that a lookup reads
@@ -236,9 +254,14 @@ struct RingCfg {
   static constexpr int gsize(int g) { int n = S::K - 1 - g * G; return n < 0 ? 0 : (n > G ? G : n); }
   static constexpr int NEED_BASE = E * (2 * R + 2 * S::K + 20 + 4 * G) + 16;   // measured VGPR demand at D = 2
   static constexpr int D = SMRF_RING_DEPTH(NEED_BASE);   // lookup groups kept in flight
-  static constexpr int inflight_after(int g) {           // lookups of groups g+1 .. g+D-1
+  static constexpr int greads(int g) {                   // LDS reads of lookup group g
     int n = 0;
-    for (int i = 1; i < D; ++i) n += gsize(g + i);
+    for (int k = 1 + g * G; k < 1 + (g + 1) * G && k < S::K; ++k) n += nreads(S::wk(k));
+    return n;
+  }
+  static constexpr int inflight_after(int g) {           // reads of groups g+1 .. g+D-1
+    int n = 0;
+    for (int i = 1; i < D; ++i) n += greads(g + i);
     return n;
   }
   static constexpr int NEED = NEED_BASE + (D - 2) * 4 * G * E;
@@ -354,7 +377,7 @@ __device__ __forceinline__ void ring_upper(typename Vec2<T>::type* const L, cons
   using C = RingCfg<T, R, TW, NP>;
   using S = typename C::S;
   using T2 = typename Vec2<T>::type;
-  constexpr int J = S::J, WP = C::WP, NLEV = C::NLEV;
+  constexpr int J = C::J, WP = C::WP, NLEV = C::NLEV;
   constexpr int JB = C::JB, SB = C::slot_of(JB);
   const unsigned lds_l = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(L + tid + OFF);
   // (3) levels JB+1 .. J from the base level: cells pos + k * 2^JB, k < 2^(J-JB).  One job per (cell position,
@@ -436,18 +459,20 @@ __device__ __forceinline__ void ring_consume(typename Vec2<T>::type* const L, co
   for (int p = 0; p < NP; ++p) {
     const unsigned q = lds_q + p * NLEV * WP * (unsigned)sizeof(T2);   // this lane's cell, level 0
     T ra[K], rb[K];                                      // window results of row A / row B per width
-    T2 ta[D][G], tb[D][G];                              // D lookup groups in flight
+    T2 ta[D][G], tb[D][G], tc[D][G];                    // D lookup groups in flight (tc: third read of the widest widths)
     auto issue = [&]<int GI>(std::integral_constant<int, GI>) {
       [&]<int... I>(std::integer_sequence<int, I...>) {
         (([&] {
            constexpr int k = 1 + GI * G + I;
            if constexpr (k < K) {
              constexpr int w = S::wk(k);
-             constexpr int j = clog2(2 * w + 1);
+             constexpr int j = C::lev(w);
              constexpr int base = C::slot_of(j) * WP;
              static_assert(C::stored(j), "lookup level not built");
              ta[GI % D][I] = lds_read2<(base - w) * (int)sizeof(T2)>(q, T());
              tb[GI % D][I] = lds_read2<(base + w - (1 << j) + 1) * (int)sizeof(T2)>(q, T());
+             if constexpr (C::nreads(w) == 3)              // window longer than two entries of the top level: one in between
+               tc[GI % D][I] = lds_read2<(base - w + (1 << j)) * (int)sizeof(T2)>(q, T());
            }
          }()), ...);
       }(std::make_integer_sequence<int, G>{});
@@ -457,8 +482,13 @@ __device__ __forceinline__ void ring_consume(typename Vec2<T>::type* const L, co
         (([&] {
            constexpr int k = 1 + GI * G + I;
            if constexpr (k < K) {
-             ra[k] = op2<DIL>(ta[GI % D][I].x, tb[GI % D][I].x);
-             rb[k] = op2<DIL>(ta[GI % D][I].y, tb[GI % D][I].y);
+             if constexpr (C::nreads(S::wk(k)) == 3) {
+               ra[k] = op3<DIL>(ta[GI % D][I].x, tc[GI % D][I].x, tb[GI % D][I].x);
+               rb[k] = op3<DIL>(ta[GI % D][I].y, tc[GI % D][I].y, tb[GI % D][I].y);
+             } else {
+               ra[k] = op2<DIL>(ta[GI % D][I].x, tb[GI % D][I].x);
+               rb[k] = op2<DIL>(ta[GI % D][I].y, tb[GI % D][I].y);
+             }
            }
          }()), ...);
       }(std::make_integer_sequence<int, G>{});
@@ -484,7 +514,7 @@ __device__ __forceinline__ void ring_consume(typename Vec2<T>::type* const L, co
     [&]<int... GI>(std::integer_sequence<int, GI...>) {
       (([&] {
          if constexpr (GI + D - 1 < NG) issue(std::integral_constant<int, GI + D - 1>{});
-         lds_wait<2 * C::inflight_after(GI)>();           // reads of the groups issued after group GI
+         lds_wait<C::inflight_after(GI)>();               // reads of the groups issued after group GI
          reduce(std::integral_constant<int, GI>{});
          if constexpr (GI == 0) {
            if constexpr (R >= 2) outv[2 * p + 1] = op3<DIL>(acc[1], ra[KR1], rb[0]);
@@ -512,7 +542,7 @@ __device__ __forceinline__ void ring_build_consume(typename Vec2<T>::type* const
   __builtin_amdgcn_s_setprio(SMRF_RING_BUILD_PRIO);
   ring_base<T, R, DIL, TW, NP, NPB, OFF>(L, par, tid, has_last, v);
   phase_sync();
-  if constexpr (RingCfg<T, R, TW, NP>::S::J > RingCfg<T, R, TW, NP>::JB) {
+  if constexpr (RingCfg<T, R, TW, NP>::J > RingCfg<T, R, TW, NP>::JB) {
     ring_upper<T, R, DIL, TW, NP, NPB, OFF>(L, tid, has_last, v);
     phase_sync();
   }

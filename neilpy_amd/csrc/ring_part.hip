@@ -24,8 +24,9 @@ namespace {
 template <int R>
 int launch_r(const DiskArgs<elem_t>& a, int mode, hipStream_t s) {
   if (mode == SMRF_RING_FUSED_OPEN) {
-    if constexpr (R <= SMRF_FUSED_MAX_RADIUS) return smrf::fused_launch<elem_t, R>(a, s);
-    else return smrf_fail(SMRF_E_UNSUPPORTED, "the fused opening covers radius <= %d (got %d)", SMRF_FUSED_MAX_RADIUS, R);
+    if constexpr (R <= smrf_fused_max_radius((int)sizeof(elem_t))) return smrf::fused_launch<elem_t, R>(a, s);
+    else return smrf_fail(SMRF_E_UNSUPPORTED, "the fused opening covers radius <= %d (got %d)",
+                          smrf_fused_max_radius((int)sizeof(elem_t)), R);
   }
   return mode == SMRF_RING_DILATE ? smrf::ring_launch<elem_t, R, true>(a, s) : smrf::ring_launch<elem_t, R, false>(a, s);
 }

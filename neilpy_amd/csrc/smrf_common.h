@@ -66,6 +66,10 @@ enum { SMRF_RING_ERODE = 0, SMRF_RING_DILATE = 1, SMRF_RING_FUSED_OPEN = 2 };
 #ifndef SMRF_FUSED_MAX_RADIUS
 #define SMRF_FUSED_MAX_RADIUS 8
 #endif
+// fp64 tables are twice as large: the fused kernel stops paying (and starts spilling) at R = 7 there
+constexpr int smrf_fused_max_radius(int elem_size) {
+  return elem_size == 4 ? SMRF_FUSED_MAX_RADIUS : (SMRF_FUSED_MAX_RADIUS < 6 ? SMRF_FUSED_MAX_RADIUS : 6);
+}
 #define SMRF_RING_PARTS 8
 #define SMRF_RING_DECL(P)                                                                     \
   SMRF_HIDDEN int smrf_ring_f32_p##P(const DiskArgs<float>&, int mode, hipStream_t);          \
