@@ -228,11 +228,15 @@ int progressive_filter_api(const T* Z, int rows, int cols, const int32_t* window
   const T* last = Z;
   // small disks: opening + flag in ONE launch, the eroded surface never leaves the CU (morph_fused.h; 10 instead of
   // 22 B/cell in fp32).  Not for rasters with NaNs (scipy's NaN rule lives in the two-pass kernels only).
-  const bool fuse_ok = !nan_aware && (impl == SMRF_IMPL_AUTO || impl == SMRF_IMPL_RING) && smrf_env_int("SMRF_FUSED", 1) != 0;
+  // SMRF_FUSED: 0 = never, 1 = default rule, 2 = every radius that has a fused kernel whatever the raster size (tests)
+  const int fuse_mode = smrf_env_int("SMRF_FUSED", 1);
+  const bool fuse_ok = !nan_aware && (impl == SMRF_IMPL_AUTO || impl == SMRF_IMPL_RING) && fuse_mode != 0;
   for (int i = 0; i < nwin; ++i) {
     const int r = windows[i];
     T* opened = O[i & 1];
-    if (fuse_ok && r >= 1 && r <= smrf_fused_max_radius((int)sizeof(T))) {   // fp64: R <= 6 (fused2_per_radius_f64.log)
+    // above R = 8 the fused kernel's 4R warm-up rows per segment only pay on rasters large enough for long segments
+    // (4096^2, windows 1..18: 1.64 ms with R <= 8 fused, 1.70 ms with 10..14 as well; 8192^2: 5.9 -> 5.2 ms with them)
+    if (fuse_ok && smrf_fused_radius((int)sizeof(T), r) && (r <= 8 || fuse_mode == 2 || plane >= ((size_t)48 << 20))) {
       DiskArgs<T> a{};
       a.in = last; a.last = last; a.out = opened; a.mask = mask; a.when = when; a.thr = thr[i]; a.widx = i;
       a.img_rows = rows; a.cols = cols; a.ld = cols; a.in_row0 = 0; a.in_rows = rows; a.out_row0 = 0; a.out_rows = rows;

@@ -19,10 +19,6 @@
 #pragma once
 #include "morph_ring.h"
 
-#ifndef SMRF_FUSED_MAX_RADIUS
-#define SMRF_FUSED_MAX_RADIUS 8
-#endif
-
 namespace smrf {
 
 // Row pairs per batch of the fused kernel (both stages), per radius.  More pairs spread the six barriers of a batch
@@ -31,7 +27,7 @@ namespace smrf {
 // stages' phases side by side under three barriers per batch (second stage one batch behind) was measured too:
 // no faster at any radius, slower at most (fused2_per_radius_f32.log), so the stages simply follow each other.
 template <typename T>
-constexpr int fused_np(int r) { return sizeof(T) == 4 ? ((r == 2 || r == 3 || r == 8) ? 1 : 2) : 1; }
+constexpr int fused_np(int r) { return sizeof(T) == 4 ? ((r == 2 || r == 3 || r == 8 || r == 10) ? 1 : 2) : 1; }
 
 template <typename T, int R, int TW, int NP>
 __global__ __launch_bounds__(TW, 4)

@@ -24,9 +24,8 @@ namespace {
 template <int R>
 int launch_r(const DiskArgs<elem_t>& a, int mode, hipStream_t s) {
   if (mode == SMRF_RING_FUSED_OPEN) {
-    if constexpr (R <= smrf_fused_max_radius((int)sizeof(elem_t))) return smrf::fused_launch<elem_t, R>(a, s);
-    else return smrf_fail(SMRF_E_UNSUPPORTED, "the fused opening covers radius <= %d (got %d)",
-                          smrf_fused_max_radius((int)sizeof(elem_t)), R);
+    if constexpr (smrf_fused_radius((int)sizeof(elem_t), R)) return smrf::fused_launch<elem_t, R>(a, s);
+    else return smrf_fail(SMRF_E_UNSUPPORTED, "no fused opening kernel for radius %d at this dtype", R);
   }
   return mode == SMRF_RING_DILATE ? smrf::ring_launch<elem_t, R, true>(a, s) : smrf::ring_launch<elem_t, R, false>(a, s);
 }

@@ -63,12 +63,16 @@ struct DiskArgs {
 // ring-kernel dispatchers, one per (dtype, radius % SMRF_RING_PARTS); defined in ring_part.hip.
 // mode: erosion, dilation (+ flag step when mask != NULL), or the fused opening + flag of morph_fused.h (in = last)
 enum { SMRF_RING_ERODE = 0, SMRF_RING_DILATE = 1, SMRF_RING_FUSED_OPEN = 2 };
+// radii whose progressive_filter window runs as ONE fused opening + flag launch (morph_fused.h), per dtype: measured
+// against the two ring passes per radius on the 16384^2 benchmark DEM (gpurun_out/r02/fused3_per_radius_f32.log,
+// fused2_per_radius_f64.log, fused_hi_f32.log).  fp32: 1..8 and 10..14 (9 loses by 3 %, 15 and up by 20 % and more);
+// fp64, whose tables are twice as large: 1..6.
 #ifndef SMRF_FUSED_MAX_RADIUS
-#define SMRF_FUSED_MAX_RADIUS 8
+#define SMRF_FUSED_MAX_RADIUS 14
 #endif
-// fp64 tables are twice as large: the fused kernel stops paying (and starts spilling) at R = 7 there
-constexpr int smrf_fused_max_radius(int elem_size) {
-  return elem_size == 4 ? SMRF_FUSED_MAX_RADIUS : (SMRF_FUSED_MAX_RADIUS < 6 ? SMRF_FUSED_MAX_RADIUS : 6);
+constexpr bool smrf_fused_radius(int elem_size, int r) {
+  if (r < 1 || r > SMRF_FUSED_MAX_RADIUS) return false;
+  return elem_size == 4 ? (r != 9) : (r <= 6);
 }
 #define SMRF_RING_PARTS 8
 #define SMRF_RING_DECL(P)                                                                     \

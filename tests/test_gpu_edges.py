@@ -207,18 +207,19 @@ def test_point_bucket_kernels_route_every_point_to_its_band(nz, gpu_device, nban
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("shape", [(1, 1), (1, 300), (300, 1), (5, 7), (33, 240), (64, 241), (100, 481), (257, 515), (700, 260)])
 def test_fused_small_disk_opening_equals_two_pass_and_oracle(nz, orc, shape, dtype, monkeypatch):
-    """windows 1..8 take the fused opening + flag kernel (morph_fused.h); SMRF_FUSED=0 forces the two-pass ring kernels.
+    """windows 1..8 and 10..14 take the fused opening + flag kernel (morph_fused.h); SMRF_FUSED=0 forces the two-pass ring kernels.
     Same bits from both, and from the oracle where scipy's reflect table is valid (radius < 4 * min(shape)): strip
     seams every 256 - 2R columns, rasters narrower than a strip, shorter than a segment's 4R warm-up rows."""
     rng = np.random.default_rng(shape[0] * 7 + shape[1])
     Z = (nz.synth_dem(max(shape[1], 8), seed=4, rows=max(shape[0], 8))[:shape[0], :shape[1]] +
          rng.normal(0, .2, shape)).astype(dtype)
-    windows = np.array([1, 2, 3, 4, 5, 6, 7, 8, 3, 1])
+    windows = np.array([1, 2, 3, 4, 5, 6, 7, 8, 3, 1, 10, 11, 12, 13, 14, 9])
+    monkeypatch.setenv("SMRF_FUSED", "2")                    # radii 10..14 too, which small rasters do not take by default
     m1, w1 = nz.progressive_filter(Z, windows, 1, .1, return_when_dropped=True)
     monkeypatch.setenv("SMRF_FUSED", "0")
     m0, w0 = nz.progressive_filter(Z, windows, 1, .1, return_when_dropped=True)
     monkeypatch.delenv("SMRF_FUSED")
     assert np.array_equal(m1, m0) and np.array_equal(w1, w0)
-    if 8 < 4 * min(shape):
+    if 14 < 4 * min(shape):
         m2, w2 = orc.progressive_filter(Z, windows, 1, .1, return_when_dropped=True)
         assert np.array_equal(m1, m2) and np.array_equal(w1, w2)
