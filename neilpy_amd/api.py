@@ -178,7 +178,7 @@ def progressive_filter(Z, windows, cellsize=1, slope_threshold=.15, return_when_
         raise OverflowError("when_dropped is uint8: more than 256 windows overflow it (as in the reference)")
     mask, when = _progressive_filter_device(Zd, windows, elevation_thresholds, return_when_dropped, impl)
     if was_tensor:
-        mask = mask.bool()
+        mask = mask.view(_torch().bool)                    # the kernels write 0 / 1: a view, not a 268 MB copy
         return (mask, when) if return_when_dropped else mask
     m = _d2h(mask).view(np.bool_)                        # the kernels write 0 / 1
     return (m, _d2h(when)) if return_when_dropped else m
@@ -460,7 +460,7 @@ def smrf(x, y, z, cellsize=1, windows=5, slope_threshold=.15, elevation_threshol
         last_stats["tail"] = _DeviceValues(elevation_values=elev_d, slope_values=slope_d)
     if _is_tensor(x) and _is_tensor(y) and _is_tensor(z):
         # CUDA tensors in -> CUDA tensors out: nothing of the result crosses PCIe
-        obj_t, pts_t = object_cells.bool(), isobj_d.bool()
+        obj_t, pts_t = object_cells.view(torch.bool), isobj_d.view(torch.bool)     # 0 / 1 bytes: views
         if not return_extras:
             return Zpro_d, t, obj_t, pts_t
         ri, ci = torch.round(r_d).long(), torch.round(c_d).long()      # round-half-even, as np.round
