@@ -1,8 +1,9 @@
 // Fused grey opening + progressive_filter flag step for the small disks (gfx950), one launch per window.
 //
 // progressive_filter (neilpy.py:1667-1676) opens `last` with disk(R) and flags `last - opened > thr`.  As two ring
-// launches that is 22 B/cell of HBM traffic in fp32 (erosion 4 + 4, dilation + flag 4 + 4 + 4 + 2); for R <= ~8
-// both launches run at the device's copy bandwidth, so the traffic is the time.  This kernel chains the two ring
+// launches that is 22 B/cell of HBM traffic in fp32 (erosion 4 + 4, dilation + flag 4 + 4 + 4 + 2); for R <= ~14
+// both launches run at or near the device's copy bandwidth, so the traffic is the time (which radii take this kernel:
+// smrf_fused_radius() in smrf_common.h, and the raster-size rule in morph.hip).  This kernel chains the two ring
 // stages of morph_ring.h inside one workgroup: the eroded rows never leave the CU (they become level 0 of the second
 // stage's table in LDS) and `last` is read from HBM once - 10 B/cell.
 //
