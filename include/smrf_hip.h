@@ -114,6 +114,22 @@ SMRF_API int smrf_pf_dilate_flag_f64(const double* d_eroded, const double* d_las
                             int in_rows, int out_row0, int out_rows, int radius, int nan_aware,
                             int impl, void* stream);
 
+/* One progressive_filter window in ONE launch for the small disks (csrc/morph_fused.h): opened =
+ * dilate(erode(last, disk(radius)), disk(radius)) and the flag step of smrf_pf_dilate_flag_*, the eroded
+ * surface never leaving the CU.  Row-band form as above, with the band of `last` reaching 2*radius rows
+ * (reflected at the raster's true borders) beyond the output rows: d_last holds global rows in_row0 ..
+ * in_row0 + in_rows - 1; d_opened, d_mask, d_when_dropped address global row out_row0; the same `last` values
+ * are used for the flag comparison.  d_mask may be NULL (opening only).  No NaN rule: the caller must not hand
+ * it rasters with NaNs.  Returns SMRF_E_UNSUPPORTED for radii without a fused kernel
+ * (smrf_fused_open_supported tells which: fp32 1..8 and 10..14, fp64 1..6). */
+SMRF_API int smrf_fused_open_supported(int elem_size, int radius);
+SMRF_API int smrf_pf_open_flag_f32(const float* d_last, float* d_opened, uint8_t* d_mask, uint8_t* d_when_dropped,
+                          double threshold, int window_index, int img_rows, int cols, int64_t ld, int in_row0,
+                          int in_rows, int out_row0, int out_rows, int radius, void* stream);
+SMRF_API int smrf_pf_open_flag_f64(const double* d_last, double* d_opened, uint8_t* d_mask, uint8_t* d_when_dropped,
+                          double threshold, int window_index, int img_rows, int cols, int64_t ld, int in_row0,
+                          int in_rows, int out_row0, int out_rows, int radius, void* stream);
+
 /* Whole progressive_filter on one device.  d_Z is read only.  h_windows / h_thresholds are HOST
  * arrays of n_windows entries; thresholds are slope_threshold*(windows*cellsize) evaluated by
  * the caller in float64 (neilpy.py:1661).  d_mask (rows*cols bytes, 0/1) and d_when_dropped

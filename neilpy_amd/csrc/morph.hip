@@ -205,6 +205,24 @@ int count_nan_api(const T* p, int64_t n, int64_t* h_count, void* stream_) {
 }
 
 template <typename T>
+int open_flag_api(const T* last, T* opened, uint8_t* mask, uint8_t* when, double thr, int widx, int img_rows, int cols,
+                  int64_t ld, int in_row0, int in_rows, int out_row0, int out_rows, int radius, void* stream) {
+  if (!smrf_fused_radius((int)sizeof(T), radius))
+    return smrf_fail(SMRF_E_UNSUPPORTED, "no fused opening kernel for radius %d at this dtype", radius);
+  DiskArgs<T> a{};
+  a.in = last; a.out = opened; a.mask = mask; a.when = when; a.thr = thr; a.widx = widx;
+  a.img_rows = img_rows; a.cols = cols; a.ld = ld;
+  a.in_row0 = in_row0; a.in_rows = in_rows; a.out_row0 = out_row0; a.out_rows = out_rows;
+  a.radius = 2 * radius;                               // the band check: `last` must reach 2r rows beyond the outputs
+  if (int rc = check_band(a)) return rc;
+  a.radius = radius;
+  a.last = last + (long long)(out_row0 - in_row0) * ld; // the flag step compares against the same surface
+  a.nan_aware = 0;
+  a.seg = smrf_env_int("SMRF_RING_SEG", 0);
+  return RingFn<T>::call(a, SMRF_RING_FUSED_OPEN, (hipStream_t)stream);
+}
+
+template <typename T>
 int progressive_filter_api(const T* Z, int rows, int cols, const int32_t* windows, const double* thr, int nwin,
                            uint8_t* mask, uint8_t* when, void* ws, size_t ws_bytes, int nan_aware, int impl,
                            void* stream_) {
@@ -237,11 +255,7 @@ int progressive_filter_api(const T* Z, int rows, int cols, const int32_t* window
     // above R = 8 the fused kernel's 4R warm-up rows per segment only pay on rasters large enough for long segments
     // (4096^2, windows 1..18: 1.64 ms with R <= 8 fused, 1.70 ms with 10..14 as well; 8192^2: 5.9 -> 5.2 ms with them)
     if (fuse_ok && smrf_fused_radius((int)sizeof(T), r) && (r <= 8 || fuse_mode == 2 || plane >= ((size_t)48 << 20))) {
-      DiskArgs<T> a{};
-      a.in = last; a.last = last; a.out = opened; a.mask = mask; a.when = when; a.thr = thr[i]; a.widx = i;
-      a.img_rows = rows; a.cols = cols; a.ld = cols; a.in_row0 = 0; a.in_rows = rows; a.out_row0 = 0; a.out_rows = rows;
-      a.radius = r; a.nan_aware = 0; a.seg = smrf_env_int("SMRF_RING_SEG", 0);
-      if (int rc = RingFn<T>::call(a, SMRF_RING_FUSED_OPEN, stream)) return rc;
+      if (int rc = open_flag_api<T>(last, opened, mask, when, thr[i], i, rows, cols, cols, 0, rows, 0, rows, r, stream_)) return rc;
       if (nwin > 1) last = opened;
       continue;
     }
@@ -285,6 +299,21 @@ int smrf_pf_dilate_flag_f64(const double* d_eroded, const double* d_last, double
   return dilate_flag_api<double>(d_eroded, d_last, d_opened, d_mask, d_when_dropped, threshold, window_index,
                                  img_rows, cols, ld, in_row0, in_rows, out_row0, out_rows, radius, nan_aware, impl,
                                  stream);
+}
+int smrf_fused_open_supported(int elem_size, int radius) { return smrf_fused_radius(elem_size, radius) ? 1 : 0; }
+int smrf_pf_open_flag_f32(const float* d_last, float* d_opened, uint8_t* d_mask, uint8_t* d_when_dropped, double threshold,
+                          int window_index, int img_rows, int cols, int64_t ld, int in_row0, int in_rows, int out_row0,
+                          int out_rows, int radius, void* stream) {
+  if (!d_last || !d_opened) return smrf_fail(SMRF_E_ARG, "null raster pointer");
+  return open_flag_api<float>(d_last, d_opened, d_mask, d_when_dropped, threshold, window_index, img_rows, cols, ld, in_row0,
+                              in_rows, out_row0, out_rows, radius, stream);
+}
+int smrf_pf_open_flag_f64(const double* d_last, double* d_opened, uint8_t* d_mask, uint8_t* d_when_dropped, double threshold,
+                          int window_index, int img_rows, int cols, int64_t ld, int in_row0, int in_rows, int out_row0,
+                          int out_rows, int radius, void* stream) {
+  if (!d_last || !d_opened) return smrf_fail(SMRF_E_ARG, "null raster pointer");
+  return open_flag_api<double>(d_last, d_opened, d_mask, d_when_dropped, threshold, window_index, img_rows, cols, ld, in_row0,
+                               in_rows, out_row0, out_rows, radius, stream);
 }
 size_t smrf_progressive_filter_workspace_bytes(int rows, int cols, int elem_size) {
   return (size_t)3 * (size_t)rows * (size_t)cols * (size_t)elem_size;

@@ -63,6 +63,21 @@ class HipBandOps:
         _lib.check(fn(C.c_void_p(band.data_ptr()), band.numel(), C.byref(cnt), self._stream()))
         return cnt.value > 0
 
+    def can_fuse(self, t, radius):
+        """a window of this radius can run as one fused opening + flag launch on a band (csrc/morph_fused.h).  Only the
+        radii whose 4r warm-up rows are short against a band's segments: r <= 8."""
+        import torch
+        return 1 <= radius <= 8 and bool(self.lib.smrf_fused_open_supported(4 if t.dtype == torch.float32 else 8, int(radius)))
+
+    def open_flag(self, last, last_row0, opened, mask, when, thr, widx, out_row0, out_rows, img_rows, radius):
+        """opened = opening(last, disk(r)) on global rows [out_row0, out_row0 + out_rows) + the flag step, one launch;
+        ``last`` holds global rows from ``last_row0`` and reaches 2r rows beyond the outputs"""
+        fn = getattr(self.lib, "smrf_pf_open_flag_" + self._sfx(last))
+        cols = last.shape[1]
+        _lib.check(fn(C.c_void_p(last.data_ptr()), C.c_void_p(opened.data_ptr()), C.c_void_p(mask.data_ptr()),
+                      C.c_void_p(when.data_ptr()) if when is not None else C.c_void_p(0), float(thr), int(widx), img_rows, cols,
+                      cols, last_row0, last.shape[0], out_row0, out_rows, int(radius), self._stream()))
+
     def erode(self, src, src_row0, dst, dst_row0, dst_rows, img_rows, radius, nan_aware=0):
         fn = getattr(self.lib, "smrf_disk_filter_" + self._sfx(src))
         _lib.check(fn(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), img_rows, src.shape[1], src.shape[1],
@@ -238,11 +253,18 @@ def progressive_filter_sharded(Z_band, img_rows, windows, thresholds, *, rank=No
                 M -= 2 * r
                 o0, o1 = max(0, b0 - M), min(img_rows, b1 + M)          # opening: r more rows inside (the band at the end)
             dst = ero[q0 - e0:q1 - e0]
-            ops.erode(last[lo - e0:hi - e0], lo, dst, q0, q1 - q0, img_rows, r, **kw)
             nxt = ext[1 - cur]
+            fused = not nan_aware and hasattr(ops, "can_fuse") and ops.can_fuse(last, r)
+            if not fused:
+                ops.erode(last[lo - e0:hi - e0], lo, dst, q0, q1 - q0, img_rows, r, **kw)
 
             def dilate(y0, y1):
                 # margin rows are flagged too (same values the neighbour computes for them); only the band's are returned
+                if fused:                                    # small disk: opening + flag of these rows in one launch
+                    ops.open_flag(last[lo - e0:hi - e0], lo, nxt[y0 - e0:y1 - e0], mask[y0 - e0:y1 - e0],
+                                  when[y0 - e0:y1 - e0] if when is not None else None, float(thresholds[i]), i, y0, y1 - y0,
+                                  img_rows, r)
+                    return
                 ops.dilate_flag(dst, q0, q1 - q0, last[y0 - e0:y1 - e0], nxt[y0 - e0:y1 - e0], mask[y0 - e0:y1 - e0],
                                 when[y0 - e0:y1 - e0] if when is not None else None, float(thresholds[i]), i, y0, y1 - y0,
                                 img_rows, r, **kw)
