@@ -30,8 +30,15 @@ namespace smrf {
 template <typename T>
 constexpr int fused_np(int r) { return sizeof(T) == 4 ? ((r == 2 || r == 3 || r == 8 || r == 10) ? 1 : 2) : 1; }
 
+// workgroups per CU the kernel is built for: what the two tables' LDS allows, at most 4 (128 registers per lane)
 template <typename T, int R, int TW, int NP>
-__global__ __launch_bounds__(TW, 4)
+constexpr int fused_min_blocks() {
+  const int by_lds = (int)(160 * 1024 / (2 * RingCfg<T, R, TW, NP>::LDS_BYTES));
+  return by_lds < 1 ? 1 : (by_lds > 4 ? 4 : by_lds);
+}
+
+template <typename T, int R, int TW, int NP>
+__global__ __launch_bounds__(TW, (fused_min_blocks<T, R, TW, NP>()))
 void fused_open_kernel(const DiskArgs<T> a) {
   using C = RingCfg<T, R, TW, NP>;
   using T2 = typename Vec2<T>::type;

@@ -41,6 +41,9 @@
 #ifndef SMRF_RING_BUILD_PRIO
 #define SMRF_RING_BUILD_PRIO 3
 #endif
+#ifndef SMRF_RING_LOOKUP_PRIO
+#define SMRF_RING_LOOKUP_PRIO 1
+#endif
 // columns (= lanes) per workgroup: 256 (shared table, barriers); tuning builds may fix 64 (wave-private table) or 512
 // (fp32 only) with -DSMRF_RING_TW=n
 #ifdef SMRF_RING_TW
@@ -458,6 +461,11 @@ __device__ __forceinline__ void ring_consume(typename Vec2<T>::type* const L, co
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     const unsigned q = lds_q + p * NLEV * WP * (unsigned)sizeof(T2);   // this lane's cell, level 0
+    // the lookup half of a pair (LDS reads + the first-half ring slots they release) above the VALU-only second
+    // half: of the SIMD's two or three waves, the one that can put reads in flight goes first and the other fills the
+    // gaps with its min3 stretch.  Measured -4...-8 % at every radius from 20 up (gpurun_out/r02/probe_prio2.log);
+    // levels 1 and 2 are equal, 3 (= the build phases' level) gives the gain back.
+    __builtin_amdgcn_s_setprio(SMRF_RING_LOOKUP_PRIO);
     T ra[K], rb[K];                                      // window results of row A / row B per width
     T2 ta[D][G], tb[D][G], tc[D][G];                    // D lookup groups in flight (tc: third read of the widest widths)
     auto issue = [&]<int GI>(std::integral_constant<int, GI>) {
@@ -523,6 +531,7 @@ __device__ __forceinline__ void ring_consume(typename Vec2<T>::type* const L, co
        }()), ...);
     }(std::make_integer_sequence<int, NG>{});
     if constexpr (R == 1) outv[2 * p + 1] = op3<DIL>(acc[1], ra[KR1], rb[0]);
+    __builtin_amdgcn_s_setprio(0);
     slots(std::integral_constant<int, NG>{});           // second half, all widths are in registers
     acc[2 * R - 2] = op2<DIL>(ra[0], rb[KR1]);
     acc[2 * R - 1] = rb[0];
