@@ -15,4 +15,5 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 tools/pmc_traffic.py > /dev/null 2> $out/pmc_write.err
 tools/ubench/op_rate $out/op_rate_table.md > $out/op_rate.log 2>&1
 tools/ubench/issue_rate $out/issue_rate_table.md > $out/issue_rate.log 2>&1
+tools/ubench/mix_rate $out/mix_rate_table.md > $out/mix_rate.log 2>&1
 ls $out/trace/*/ | head
