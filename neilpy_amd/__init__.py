@@ -6,7 +6,7 @@ in hand-written gfx950 HIP kernels in ``libsmrf_hip.so`` (C ABI: ``include/smrf_
 there is no CPU fallback.
 """
 from ._lib import SmrfHipError, load as load_library, LIB_PATH          # noqa: F401
-from .affine import Affine, from_origin, write_worldfile                 # noqa: F401
+from .affine import Affine, edges_from_IT, from_origin, write_worldfile                 # noqa: F401
 from .api import (create_dem, dilation, disk, erosion, inpaint_nans_by_fda, inpaint_nans_by_springs,   # noqa: F401
                   last_stats,
                   opening, progressive_filter, pssm, smrf)

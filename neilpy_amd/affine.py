@@ -54,6 +54,22 @@ def from_origin(west, north, xsize, ysize):
     return Affine(1.0, 0.0, west, 0.0, 1.0, north) * Affine(xsize, 0.0, 0.0, 0.0, -ysize, 0.0)
 
 
+def edges_from_IT(Image, Transform):
+    """neilpy.edges_from_IT (neilpy/neilpy.py:1095-1102): the x and y cell edges of a raster with transform
+    ``Transform`` - pixel corners (0..cols, 0) and (0, 0..rows) mapped to world coordinates - in the form
+    ``create_dem(..., edges=(x_edges, y_edges))`` takes, so that a second cloud is gridded onto the first one's cells.
+    Host arithmetic on rows + cols + 2 values; ``Image`` only gives the shape (array, tensor or anything with ``.shape``)."""
+    import numpy as np
+    shape = getattr(Image, "shape", None) or np.shape(Image)
+    r, c = int(shape[0]), int(shape[1])
+    j, i = np.arange(c + 1), np.arange(r + 1)
+    sa, sb, sc, sd, se, sf = (float(v) for v in tuple(Transform)[:6])
+    # the same expression order as affine's __mul__ on a (vx, vy) pair: vx * a + vy * b + c, vx * d + vy * e + f
+    x_edges = j * sa + np.zeros_like(j) * sb + sc
+    y_edges = np.zeros_like(i) * sd + i * se + sf
+    return x_edges, y_edges
+
+
 def write_worldfile(affine_matrix, output_file):
     """neilpy.write_worldfile (neilpy/neilpy.py:1564-1570): the six world-file lines (pixel width,
     column rotation, row rotation, pixel height, x and y of the centre of the upper-left pixel),

@@ -105,6 +105,15 @@ def create_dem(x, y, z, cellsize=1, bin_type='max', inpaint=False, edges=None):
     return I, t
 
 
+def edges_from_IT(Image, Transform):                                 # neilpy/neilpy.py:1095-1102
+    """Cell edges of a raster from its transform: the pixel corners (j, 0) and (0, i) pushed through ``Transform``."""
+    r, c = np.shape(Image)[0], np.shape(Image)[1]
+    j, i = np.arange(c + 1), np.arange(r + 1)
+    x_edges, _ = Transform * (j, np.zeros_like(j))
+    _, y_edges = Transform * (np.zeros_like(i), i)
+    return x_edges, y_edges
+
+
 # ----------------------------------------------------------------------------
 # inpaint_nans_by_springs (neilpy.py:1227-1271) with LSQR (scipy lsqr.py)
 # ----------------------------------------------------------------------------

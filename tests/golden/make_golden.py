@@ -514,6 +514,29 @@ def golden_create_dem_samples(ref, out):
     np.savez_compressed(os.path.join(out, "create_dem_samples.npz"), **d)
 
 
+def golden_edges(ref, out):
+    """edges_from_IT (neilpy.py:1095-1102) on the transforms create_dem returns, and the round trip the helper exists
+    for: create_dem(x, y, z, edges=edges_from_IT(I, t)) rebuilds I on the same grid."""
+    d, cases = {}, []
+    x, y, z, _ = load_sample("samp11")
+    for cs, tag in ((1, "cs1"), (0.3, "cs0p3"), (2.5, "cs2p5")):
+        I, t = ref.create_dem(x, y, z, cellsize=cs, bin_type="min")
+        xe, ye = ref.edges_from_IT(I, t)
+        I2, t2 = ref.create_dem(x, y, z, bin_type="min", edges=(xe, ye))
+        d[tag + "_shape"] = np.array(I.shape)
+        d[tag + "_transform"] = np.array(t[:6], dtype=np.float64)
+        d[tag + "_xedges"], d[tag + "_yedges"] = np.asarray(xe, dtype=np.float64), np.asarray(ye, dtype=np.float64)
+        d[tag + "_roundtrip_shape"] = np.array(I2.shape)
+        d[tag + "_roundtrip_transform"] = np.array(t2[:6], dtype=np.float64)
+        same = I2.shape == I.shape and np.array_equal(I, I2, equal_nan=True)
+        d[tag + "_roundtrip_equal"] = np.array(bool(same))
+        d[tag + "_roundtrip_I_centi"] = np.where(np.isnan(I2), -2 ** 31, np.round(np.nan_to_num(I2) * 100.0)).astype(np.int32)
+        cases.append(tag)
+        print("edges_from_IT", tag, I.shape, "->", I2.shape, "equal" if same else "differs", flush=True)
+    d["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(out, "edges.npz"), **d)
+
+
 def golden_las(ref, out):
     """LAS files written by neilpy_amd.las.write_las (formats 0-10, LAS 1.2/1.3/1.4), read back by the
     REFERENCE's read_las: header dictionary and every DataFrame column are the golden."""
@@ -603,6 +626,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "create_dem_samples":
         golden_create_dem_samples(ref, out)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "edges":
+        golden_edges(ref, out)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "fda":
         golden_fda(ref, Recorder(ref), out)
         return
@@ -613,6 +639,7 @@ def main():
     golden_fda(ref, rec, out)
     golden_create_dem(ref, rec, out)
     golden_create_dem_samples(ref, out)
+    golden_edges(ref, out)
     golden_las(ref, out)
     golden_pssm(ref, out)
     anchors, published = golden_smrf(ref, rec, out)

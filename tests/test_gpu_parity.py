@@ -189,6 +189,24 @@ def test_create_dem_samples_noninteger_cellsize(nz, tag):
     assert np.array_equal(I, zmin_from_centi(CDS[tag + "_I_centi"]), equal_nan=True)
 
 
+EDG = golden("edges.npz")
+
+
+@pytest.mark.parametrize("tag", [str(c) for c in EDG["cases"]])
+def test_create_dem_on_edges_from_IT(nz, tag):
+    """create_dem(x, y, z, edges=edges_from_IT(I, t)) - a second gridding onto the first one's cells (neilpy.py:1095-1102,
+    :1125-1132): the reference's grid and transform, bit-exact; the grid is also the one create_dem built without edges"""
+    x, y, z, _ = load_sample("samp11")
+    cs = {"cs1": 1, "cs0p3": .3, "cs2p5": 2.5}[tag]
+    I, t = nz.create_dem(x, y, z, cellsize=cs, bin_type="min")
+    xe, ye = nz.edges_from_IT(I, t)
+    assert np.array_equal(xe, EDG[tag + "_xedges"]) and np.array_equal(ye, EDG[tag + "_yedges"])
+    I2, t2 = nz.create_dem(x, y, z, bin_type="min", edges=(xe, ye))
+    assert np.array_equal(np.array(tuple(t2)[:6]), EDG[tag + "_roundtrip_transform"])
+    assert np.array_equal(I2, zmin_from_centi(EDG[tag + "_roundtrip_I_centi"]), equal_nan=True)
+    assert np.array_equal(I2, I, equal_nan=True)
+
+
 def test_create_dem_errors(nz):
     with pytest.raises(ValueError, match="This type not supported."):
         nz.create_dem(np.array([0., 1.]), np.array([0., 1.]), np.array([0., 1.]), bin_type="mean")
