@@ -1,0 +1,46 @@
+"""Static checks of the generated gfx950 code (no GPU): the ring kernels issue their LDS table reads as inline asm and count
+the s_waitcnt themselves, so nothing but this scan protects a register between a read's issue and the wait that covers it
+(tools/check_isa.py checks every translation unit; here: the scanner itself and the unit that holds the R = 50 kernels)."""
+import importlib.util
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("check_isa", os.path.join(ROOT, "tools", "check_isa.py"))
+check_isa = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(check_isa)
+
+
+def test_scanner_finds_a_use_before_the_wait():
+    asm = """_ZN4test:
+	ds_read_b64 v[4:5], v1 offset:8
+	ds_read_b64 v[6:7], v1 offset:16
+	s_waitcnt lgkmcnt(1)
+	v_min_f32_e32 v8, v4, v5
+	v_min_f32_e32 v9, v6, v7
+	s_waitcnt lgkmcnt(0)
+	v_min_f32_e32 v9, v6, v7
+	s_endpgm
+"""
+    hz = check_isa.lds_hazards(asm)
+    assert len(hz) == 1 and "v6" in hz[0] and "line 6" in hz[0]
+    spill = asm.replace("\tv_min_f32_e32 v9, v6, v7\n\ts_waitcnt lgkmcnt(0)", "\tscratch_store_dword off, v7, off\n\ts_waitcnt lgkmcnt(0)")
+    assert len(check_isa.lds_hazards(spill)) == 1
+    overwrite = asm.replace("\tv_min_f32_e32 v9, v6, v7\n\ts_waitcnt lgkmcnt(0)", "\tv_mov_b32_e32 v6, 0\n\ts_waitcnt lgkmcnt(0)")
+    assert len(check_isa.lds_hazards(overwrite)) == 1
+
+
+def test_ring_unit_has_no_inflight_use_and_no_fused_lds_ops(tmp_path):
+    from neilpy_amd.build import CSRC, FLAGS, hipcc
+    out = str(tmp_path / "ring_f32_p2.s")
+    cmd = [hipcc()] + [f for f in FLAGS if f != "-fPIC"] + ["-DPART=2", "-DSMRF_F64=0", "--offload-device-only", "-S",
+                                                           os.path.join(CSRC, "ring_part.hip"), "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = open(out).read()
+    assert text.count("ds_read_b64") > 1000                # radii 2, 10, ..., 58: the scan has something to look at
+    assert check_isa.lds_hazards(text) == []
+    assert "ds_read2" not in text and "ds_write2" not in text

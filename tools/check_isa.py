@@ -19,6 +19,69 @@ sys.path.insert(0, ROOT)
 from neilpy_amd.build import CSRC, FLAGS, RING_PARTS, hipcc  # noqa: E402
 
 
+_VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+_DEST_FIRST = re.compile(r"^(v_(?!cmp|cmpx|readlane|readfirstlane|nop)|ds_read|ds_bpermute|ds_permute|ds_swizzle|global_load|scratch_load|buffer_load|flat_load|"
+                         r"global_atomic\w+ v|v_accvgpr_read)")
+
+
+def _regs(tok):
+    out = []
+    for m in _VREG.finditer(tok):
+        if m.group(1) is not None:
+            out.append(int(m.group(1)))
+        else:
+            out += list(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def lds_hazards(text):
+    """Reads of (or writes to) a VGPR that an earlier ds_read is still filling: the kernels issue their table reads as
+    inline asm and count the s_waitcnt themselves, so neither the compiler's own bookkeeping nor the hardware protects
+    a register between the read's issue and the wait that covers it - a spill, a copy or a miscounted wait in that window
+    would use stale data.  Linear scan per kernel: LDS operations retire in order, s_waitcnt lgkmcnt(N) leaves the N
+    youngest outstanding (scalar loads only make it stricter)."""
+    bad = []
+    kern = None
+    pending = []                                           # outstanding LDS ops, oldest first: lists of dest VGPRs
+    for ln, line in enumerate(text.splitlines(), 1):
+        if line.startswith("_ZN") and line.rstrip().endswith(":"):
+            kern, pending = line.split(":")[0], []
+            continue
+        if kern is None:
+            continue
+        st = line.strip()
+        if not st or st[0] in ";.":
+            if st.startswith(".end_amdhsa_kernel") or st.startswith(".Lfunc_end"):
+                kern = None
+            continue
+        st = st.split(";")[0].strip()
+        op = st.split()[0]
+        args = st[len(op):]
+        if op == "s_waitcnt":
+            m = re.search(r"lgkmcnt\((\d+)\)", args)
+            if m:
+                n = int(m.group(1))
+                if n < len(pending):
+                    pending = pending[len(pending) - n:] if n else []
+            elif "vmcnt" not in args and "expcnt" not in args:   # bare immediate form: treat as full wait
+                pending = []
+            continue
+        if op in ("s_barrier", "s_endpgm"):
+            continue
+        toks = [t.strip() for t in args.split(",")]
+        dest_first = bool(_DEST_FIRST.match(op)) and "store" not in op and not op.startswith("ds_write")
+        srcs, dsts = [], []
+        for i, t in enumerate(toks):
+            (dsts if (i == 0 and dest_first) else srcs).extend(_regs(t))
+        busy = {r for d in pending for r in d}
+        hit = [r for r in srcs + dsts if r in busy]
+        if hit:
+            bad.append("LDS read still in flight into v%d when `%s` uses it, in %s (asm line %d)" % (hit[0], st, kern, ln))
+        if op.startswith("ds_"):
+            pending.append(dsts if op.startswith(("ds_read", "ds_bpermute", "ds_permute", "ds_swizzle")) else [])
+    return bad
+
+
 def one(job):
     part, f64, tmp = job
     out = os.path.join(tmp, "ring_%d_%d.s" % (f64, part))
@@ -41,6 +104,8 @@ def one(job):
         if mm and kern:
             fused[(kern, mm.group(1))] = fused.get((kern, mm.group(1)), 0) + 1
     bad += ["%d x %s in %s" % (n, op, k) for (k, op), n in fused.items()]
+    hz = lds_hazards(text)
+    bad += hz[:5] + (["... and %d more in-flight uses" % (len(hz) - 5)] if len(hz) > 5 else [])
     return part, f64, bad
 
 
