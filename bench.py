@@ -99,7 +99,7 @@ def main():
     Z_host = neilpy_amd.synth_dem(n, seed=20240, dtype=np_dtype, row_range=(b0, b1))
     Z = torch.from_numpy(Z_host).to(dev)
     crop = None
-    if rank == 0 and not a.no_cpu and a.cpu_crop > 0:
+    if rank == 0 and world == 1 and not a.no_cpu and a.cpu_crop > 0:   # the CPU figure belongs to the N = 1 line only
         c = min(a.cpu_crop, n, b1 - b0)
         crop = np.ascontiguousarray(Z_host[:c, :c])
     del Z_host
