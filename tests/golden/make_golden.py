@@ -537,6 +537,24 @@ def golden_edges(ref, out):
     np.savez_compressed(os.path.join(out, "edges.npz"), **d)
 
 
+DROP_IN = ["smrf", "progressive_filter", "create_dem", "inpaint_nans_by_springs", "inpaint_nans_by_fda", "read_las", "pssm",
+           "write_worldfile", "edges_from_IT"]
+
+
+def golden_signatures(ref, out):
+    """The call signatures of the reference's functions this package is a drop-in for: parameter names in order, kinds and
+    defaults (repr) - the boundary of SURVEY 8b, checked against neilpy_amd's by tests/test_abi.py."""
+    import inspect
+    sig = {}
+    for name in DROP_IN:
+        ps = inspect.signature(getattr(ref, name)).parameters.values()
+        sig[name] = [dict(name=p.name, kind=p.kind.name, default=None if p.default is inspect.Parameter.empty else repr(p.default))
+                     for p in ps]
+    with open(os.path.join(out, "signatures.json"), "w") as f:
+        json.dump(sig, f, indent=1, sort_keys=True)
+    print("signatures", {k: len(v) for k, v in sig.items()})
+
+
 def golden_las(ref, out):
     """LAS files written by neilpy_amd.las.write_las (formats 0-10, LAS 1.2/1.3/1.4), read back by the
     REFERENCE's read_las: header dictionary and every DataFrame column are the golden."""
@@ -626,6 +644,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "create_dem_samples":
         golden_create_dem_samples(ref, out)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "signatures":
+        golden_signatures(ref, out)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "edges":
         golden_edges(ref, out)
         return
@@ -640,6 +661,7 @@ def main():
     golden_create_dem(ref, rec, out)
     golden_create_dem_samples(ref, out)
     golden_edges(ref, out)
+    golden_signatures(ref, out)
     golden_las(ref, out)
     golden_pssm(ref, out)
     anchors, published = golden_smrf(ref, rec, out)

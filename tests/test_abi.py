@@ -68,3 +68,25 @@ def test_device_scope_refuses_mixed_devices():
     assert common_device([a, c, "x", a]) == "cuda:0"
     with pytest.raises(SmrfHipError, match="different devices"):
         common_device([a, 3, b])
+
+
+def test_drop_in_signatures_match_the_reference():
+    """Every function neilpy_amd re-exports under a neilpy name takes the reference's parameters - same names, same
+    order, same defaults (tests/golden/signatures.json, written by make_golden.py from the imported reference);
+    anything this package adds is keyword-only, so a positional neilpy call means the same thing here."""
+    import inspect
+    import json
+    import os
+
+    import neilpy_amd
+    from conftest import GOLDEN
+    want = json.load(open(os.path.join(GOLDEN, "signatures.json")))
+    assert set(want) >= {"smrf", "progressive_filter", "create_dem", "inpaint_nans_by_springs"}
+    for name, params in want.items():
+        got = list(inspect.signature(getattr(neilpy_amd, name)).parameters.values())
+        for i, p in enumerate(params):
+            g = got[i]
+            assert (g.name, g.kind.name) == (p["name"], p["kind"]), (name, i, g, p)
+            assert (None if g.default is inspect.Parameter.empty else repr(g.default)) == p["default"], (name, g, p)
+        for g in got[len(params):]:
+            assert g.kind is inspect.Parameter.KEYWORD_ONLY, (name, g)
