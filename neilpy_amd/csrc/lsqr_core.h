@@ -31,6 +31,12 @@ struct Sc {
   for (int r = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x; r < (rows_); r += gridDim.y) \
     for (long long i = (long long)r * (cols_) + c; c < (cols_) && i >= 0; i = -1)
 
+// the same walk over planes whose rows are ld_ >= cols_ cells apart (i indexes the padded planes; same cells per thread in the
+// same order as SMRF_FOR_CELLS, so every partial sum is bit-identical whatever the pitch)
+#define SMRF_FOR_CELLS_P(rows_, cols_, ld_)                                                  \
+  for (int r = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x; r < (rows_); r += gridDim.y) \
+    for (long long i = (long long)r * (ld_) + c; c < (cols_) && i >= 0; i = -1)
+
 __device__ __forceinline__ double block_sum(double s, double* red) {
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
   const int w = threadIdx.x >> 6;

@@ -35,21 +35,23 @@ struct Band {
   double* red;        // red[0]: the phase's sum (local; the host all-reduces it between phases)
   Sc* sc;
   int rows, cols, has_above, has_below;
+  long long ld;       // cells between plane rows (>= cols; the raster A itself is always cols apart)
 };
 
 
 // ---- setup ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mask_kernel(const double* __restrict__ A, const Band b) {
   __shared__ double red[4];
-  const long long n = (long long)b.rows * b.cols;
-  double c = 0.0;
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const double a = A[i];
+  const int rows = b.rows, cols = b.cols;
+  const long long ld = b.ld;
+  double c_holes = 0.0;
+  SMRF_FOR_CELLS_P(rows, cols, ld) {
+    const double a = A[(long long)r * cols + c];
     const bool h = a != a;
     b.hole[i] = h;
-    c += h ? 1.0 : 0.0;
+    c_holes += h ? 1.0 : 0.0;
   }
-  const double t = block_sum(c, red);
+  const double t = block_sum(c_holes, red);
   if (threadIdx.x == 0) b.part[blockIdx.y * gridDim.x + blockIdx.x] = t;
 }
 
@@ -57,19 +59,20 @@ __global__ __launch_bounds__(256) void mask_kernel(const double* __restrict__ A,
 __global__ __launch_bounds__(256) void rhs_kernel(const double* __restrict__ A, const Band b) {
   __shared__ double red[4];
   const int rows = b.rows, cols = b.cols;
-  const long long n = (long long)rows * cols;
+  const long long ld = b.ld;
   double s = 0.0;
-  SMRF_FOR_CELLS(rows, cols) {
+  SMRF_FOR_CELLS_P(rows, cols, ld) {
+    const long long ia = (long long)r * cols + c;        // A is cols apart, the planes ld
     const bool h0 = b.hole[i];
-    const double k0 = h0 ? 0.0 : A[i];
+    const double k0 = h0 ? 0.0 : A[ia];
     double eh = 0.0, ev = 0.0;
     if (c + 1 < cols) {
       const bool h1 = b.hole[i + 1];
-      if (h0 | h1) eh = (h1 ? 0.0 : A[i + 1]) - k0;
+      if (h0 | h1) eh = (h1 ? 0.0 : A[ia + 1]) - k0;
     }
     if (r + 1 < rows || b.has_below) {
-      const bool h1 = b.hole[i + cols];
-      const double a1 = r + 1 < rows ? A[i + cols] : b.abelow[c];
+      const bool h1 = b.hole[i + ld];
+      const double a1 = r + 1 < rows ? A[ia + cols] : b.abelow[c];
       if (h0 | h1) ev = (h1 ? 0.0 : a1) - k0;
     }
     b.uh[i] = eh;
@@ -114,12 +117,12 @@ __global__ __launch_bounds__(256) void atu_kernel(const Band b) {
   if (stopped(sc) || !sc->beta_pos) return;
   const double ib = sc->inv_beta, ia = sc->inv_alfa, beta = sc->beta;
   const int rows = b.rows, cols = b.cols;
-  const long long n = (long long)rows * cols;
+  const long long ld = b.ld;
   double s = 0.0, sw = 0.0;
-  SMRF_FOR_CELLS(rows, cols) {
+  SMRF_FOR_CELLS_P(rows, cols, ld) {
     if (!b.hole[i]) continue;
     double y = 0.0;
-    if (r > 0 || b.has_above) y = y - ib * b.uv[i - cols];
+    if (r > 0 || b.has_above) y = y - ib * b.uv[i - ld];
     if (c > 0) y = y - ib * b.uh[i - 1];
     if (c + 1 < cols) y = y + ib * b.uh[i];
     if (r + 1 < rows || b.has_below) y = y + ib * b.uv[i];
@@ -161,8 +164,7 @@ __global__ void s_init_alfa(const Band b) {
 __global__ __launch_bounds__(256) void w_init_kernel(const Band b) {
   if (b.sc->done) return;
   const double ia = b.sc->inv_alfa;
-  const long long n = (long long)b.rows * b.cols;
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) b.w[i] = ia * b.v[i];
+  SMRF_FOR_CELLS_P(b.rows, b.cols, b.ld) b.w[i] = ia * b.v[i];
 }
 
 // ---- u = S v_s - alfa * u_s, partial |u|^2 ---------------------------------------------------
@@ -172,9 +174,9 @@ __global__ __launch_bounds__(256) void av_kernel(const Band b) {
   if (stopped(sc)) return;
   const double ib = sc->inv_beta, ia = sc->inv_alfa, alfa = sc->alfa;
   const int rows = b.rows, cols = b.cols;
-  const long long n = (long long)rows * cols;
+  const long long ld = b.ld;
   double s = 0.0;
-  SMRF_FOR_CELLS(rows, cols) {
+  SMRF_FOR_CELLS_P(rows, cols, ld) {
     // v[i] is read before the hole tests on purpose: making it (or a per-tile activity byte) conditional turns
     // independent loads into dependent ones and measured 4-10 % SLOWER on 8192^2 at every hole pattern
     // (gpurun_out/r02/lsqr_ab*.log); planes of known-only regions are never touched as it is.
@@ -188,8 +190,8 @@ __global__ __launch_bounds__(256) void av_kernel(const Band b) {
       }
     }
     if (r + 1 < rows || b.has_below) {
-      if (h0 | b.hole[i + cols]) {
-        const double nu = (v0 - ia * b.v[i + cols]) - alfa * (ib * b.uv[i]);
+      if (h0 | b.hole[i + ld]) {
+        const double nu = (v0 - ia * b.v[i + ld]) - alfa * (ib * b.uv[i]);
         b.uv[i] = nu;
         s += nu * nu;
       }
@@ -215,9 +217,8 @@ __global__ __launch_bounds__(256) void xw_kernel(const Band b) {
   const Sc* sc = b.sc;
   if (stopped(sc)) return;
   const double t1 = sc->t1, t2 = sc->t2, ir = sc->inv_rho, ia = sc->inv_alfa;
-  const long long n = (long long)b.rows * b.cols;
   double s = 0.0;
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+  SMRF_FOR_CELLS_P(b.rows, b.cols, b.ld) {
     if (!b.hole[i]) continue;
     const double ws = b.w[i];
     const double dk = ir * ws;
@@ -245,9 +246,9 @@ __global__ __launch_bounds__(256) void xwav_kernel(const Band b) {
   if (stopped(sc)) return;
   const double t1 = sc->t1, t2 = sc->t2, ir = sc->inv_rho, ia = sc->inv_alfa, ib = sc->inv_beta, alfa = sc->alfa;
   const int rows = b.rows, cols = b.cols;
-  const long long n = (long long)rows * cols;
+  const long long ld = b.ld;
   double sd = 0.0, su = 0.0;
-  SMRF_FOR_CELLS(rows, cols) {
+  SMRF_FOR_CELLS_P(rows, cols, ld) {
     const bool h0 = b.hole[i];
     const double v0 = ia * b.v[i];                       // unconditional on purpose (see av_kernel)
     if (h0) {
@@ -265,8 +266,8 @@ __global__ __launch_bounds__(256) void xwav_kernel(const Band b) {
       }
     }
     if (r + 1 < rows) {
-      if (h0 | b.hole[i + cols]) {
-        const double nu = (v0 - ia * b.v[i + cols]) - alfa * (ib * b.uv[i]);
+      if (h0 | b.hole[i + ld]) {
+        const double nu = (v0 - ia * b.v[i + ld]) - alfa * (ib * b.uv[i]);
         b.uv[i] = nu;
         su += nu * nu;
       }
@@ -278,9 +279,8 @@ __global__ __launch_bounds__(256) void xwav_kernel(const Band b) {
 }
 
 __global__ __launch_bounds__(256) void scatter_kernel(double* __restrict__ A, const Band b) {
-  const long long n = (long long)b.rows * b.cols;
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-    if (b.hole[i]) A[i] = b.x[i];
+  SMRF_FOR_CELLS_P(b.rows, b.cols, b.ld)
+    if (b.hole[i]) A[(long long)r * b.cols + c] = b.x[i];
 }
 
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -290,9 +290,21 @@ size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 struct Layout {
   size_t plane, x, v, w, uh, uv, hole, abelow, part, red, sc, total;
 };
-Layout layout_of(int rows, int cols) {
+// Plane pitch of the single-device solver.  create_dem's grids are one cell wider than a round number as a rule, so rows of
+// cols doubles start anywhere in a cache line.  Rows padded to 32 doubles (256 B) measure 2-5 % faster per iteration at 2049 ...
+// 16385 columns; on 32769 columns (1.07e9 cells, 8.6 GB per plane) a 4 KB pitch is worth 11 % (26.6 -> 23.6 ms per iteration
+// against 22.3 ms on 32768 columns) while it costs 5-9 % at 8193 and 16385 (gpurun_out/r02/lsqr_pitch3.log, lsqr_pitch4.log),
+// hence the size rule.  Pad cells are never touched; every thread walks the same cells in the same order as without padding, so
+// all sums, the stop iteration and the result are bit-identical.  The band form keeps ld = cols: its halo rows are addressed by
+// the host (neilpy_amd/sharded.py) through smrf_springs_band_layout.
+long long padded_pitch(int cols) {
+  const long long a = cols >= 24576 ? 512 : 32;
+  return (((long long)cols + a - 1) / a) * a;
+}
+
+Layout layout_of(int rows, int cols, long long ld) {
   Layout L;
-  const size_t n2 = (size_t)(rows + 2) * (size_t)cols;
+  const size_t n2 = (size_t)(rows + 2) * (size_t)ld;
   L.plane = align_up(n2 * sizeof(double));
   size_t o = 0;
   L.x = o; o += L.plane;
@@ -308,28 +320,23 @@ Layout layout_of(int rows, int cols) {
   L.total = o;
   return L;
 }
-Band band_of(void* ws, int rows, int cols, int has_above, int has_below) {
-  const Layout L = layout_of(rows, cols);
+Band band_of(void* ws, int rows, int cols, long long ld, int has_above, int has_below) {
+  const Layout L = layout_of(rows, cols, ld);
   char* p = (char*)ws;
   Band b;
-  b.x = (double*)(p + L.x) + cols;
-  b.v = (double*)(p + L.v) + cols;
-  b.w = (double*)(p + L.w) + cols;
-  b.uh = (double*)(p + L.uh) + cols;
-  b.uv = (double*)(p + L.uv) + cols;
-  b.hole = (uint8_t*)(p + L.hole) + cols;
+  b.x = (double*)(p + L.x) + ld;
+  b.v = (double*)(p + L.v) + ld;
+  b.w = (double*)(p + L.w) + ld;
+  b.uh = (double*)(p + L.uh) + ld;
+  b.uv = (double*)(p + L.uv) + ld;
+  b.hole = (uint8_t*)(p + L.hole) + ld;
   b.abelow = (double*)(p + L.abelow);
   b.part = (double*)(p + L.part);
   b.red = (double*)(p + L.red);
   b.sc = (Sc*)(p + L.sc);
-  b.rows = rows; b.cols = cols; b.has_above = has_above; b.has_below = has_below;
+  b.rows = rows; b.cols = cols; b.ld = ld; b.has_above = has_above; b.has_below = has_below;
   return b;
 }
-int nblocks(const Band& b) {
-  const long long n = (long long)b.rows * b.cols;
-  return (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, MAXB));
-}
-
 enum Phase {
   PH_MASK = 0,      // hole mask of own rows, red[0] = local unknown count
   PH_RHS = 1,       // (after hole/A halo + count all-reduce) rhs, red[0] = local |b|^2
@@ -352,12 +359,11 @@ dim3 grid2d(const Band& b) {
 }
 
 int run_phase(int phase, double* A, const Band& b, hipStream_t st) {
-  const int nb = nblocks(b);
   const dim3 g2 = grid2d(b);
   const int nb2 = (int)(g2.x * g2.y);
   auto reduce = [&](int count) { hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(256), 0, st, (const double*)b.part, count, b.red); };
   switch (phase) {
-    case PH_MASK: hipLaunchKernelGGL(mask_kernel, dim3(nb), dim3(256), 0, st, (const double*)A, b); reduce(nb); break;
+    case PH_MASK: hipLaunchKernelGGL(mask_kernel, g2, dim3(256), 0, st, (const double*)A, b); reduce(nb2); break;
     case PH_RHS:
       hipLaunchKernelGGL(s_count, dim3(1), dim3(1), 0, st, b);
       hipLaunchKernelGGL(rhs_kernel, g2, dim3(256), 0, st, (const double*)A, b);
@@ -370,14 +376,14 @@ int run_phase(int phase, double* A, const Band& b, hipStream_t st) {
       break;
     case PH_INIT_ALFA:
       hipLaunchKernelGGL(s_init_alfa, dim3(1), dim3(1), 0, st, b);
-      hipLaunchKernelGGL(w_init_kernel, dim3(nb), dim3(256), 0, st, b);
+      hipLaunchKernelGGL(w_init_kernel, g2, dim3(256), 0, st, b);
       break;
     case PH_AV: hipLaunchKernelGGL(av_kernel, g2, dim3(256), 0, st, b); reduce(nb2); break;
     case PH_BETA: hipLaunchKernelGGL(s_beta, dim3(1), dim3(1), 0, st, b); break;
     case PH_ALFA_ROT: hipLaunchKernelGGL(s_alfa_rot, dim3(1), dim3(1), 0, st, b); break;
-    case PH_XW: hipLaunchKernelGGL(xw_kernel, dim3(nb), dim3(256), 0, st, b); break;   // its sum rode with PH_ATU's
+    case PH_XW: hipLaunchKernelGGL(xw_kernel, g2, dim3(256), 0, st, b); break;   // its sum rode with PH_ATU's
     case PH_TESTS: hipLaunchKernelGGL(s_tests, dim3(1), dim3(1), 0, st, b); break;
-    case PH_SCATTER: hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, st, A, b); break;
+    case PH_SCATTER: hipLaunchKernelGGL(scatter_kernel, g2, dim3(256), 0, st, A, b); break;
     default: return smrf_fail(SMRF_E_ARG, "unknown springs phase %d", phase);
   }
   SMRF_LAUNCH_CHECK();
@@ -397,7 +403,7 @@ int init_scalars(const Band& b, double atol, double btol, double conlim, int64_t
 
 extern "C" {
 
-size_t smrf_springs_workspace_bytes(int rows, int cols) { return layout_of(rows, cols).total; }
+size_t smrf_springs_workspace_bytes(int rows, int cols) { return layout_of(rows, cols, padded_pitch(cols)).total; }
 
 int smrf_springs_lsqr_f64(double* d_A, int rows, int cols, double atol, double btol, double conlim,
                           int64_t iter_lim, int* h_istop, int64_t* h_itn, int64_t* h_n_unknown,
@@ -407,7 +413,7 @@ int smrf_springs_lsqr_f64(double* d_A, int rows, int cols, double atol, double b
   if (rows < 1 || cols < 1) return smrf_fail(SMRF_E_ARG, "bad raster size %d x %d", rows, cols);
   if (!d_workspace || workspace_bytes < smrf_springs_workspace_bytes(rows, cols))
     return smrf_fail(SMRF_E_WORKSPACE, "springs workspace too small");
-  const Band b = band_of(d_workspace, rows, cols, 0, 0);
+  const Band b = band_of(d_workspace, rows, cols, padded_pitch(cols), 0, 0);
   if (int rc = init_scalars(b, atol, btol, conlim, iter_lim, stream)) return rc;
   for (int ph : {PH_MASK, PH_RHS, PH_BNORM, PH_ATU, PH_INIT_ALFA})
     if (int rc = run_phase(ph, d_A, b, stream)) return rc;
@@ -447,11 +453,11 @@ int smrf_springs_lsqr_f64(double* d_A, int rows, int cols, double atol, double b
   return SMRF_OK;
 }
 
-size_t smrf_springs_band_workspace_bytes(int rows_local, int cols) { return layout_of(rows_local, cols).total; }
+size_t smrf_springs_band_workspace_bytes(int rows_local, int cols) { return layout_of(rows_local, cols, cols).total; }
 
 int smrf_springs_band_layout(int rows_local, int cols, int64_t* h_out) {
   if (!h_out || rows_local < 1 || cols < 1) return smrf_fail(SMRF_E_ARG, "bad band");
-  const Layout L = layout_of(rows_local, cols);
+  const Layout L = layout_of(rows_local, cols, cols);
   h_out[0] = (int64_t)L.v;       // v plane    (rows_local + 2 rows of cols doubles, row 0 = halo above)
   h_out[1] = (int64_t)L.uv;      // uv plane   (same shape)
   h_out[2] = (int64_t)L.hole;    // hole plane (rows_local + 2 rows of cols bytes)
@@ -464,26 +470,26 @@ int smrf_springs_band_layout(int rows_local, int cols, int64_t* h_out) {
 int smrf_springs_band_begin(int rows_local, int cols, double atol, double btol, double conlim, int64_t iter_lim,
                             void* d_workspace, size_t workspace_bytes, void* stream) {
   if (rows_local < 1 || cols < 1) return smrf_fail(SMRF_E_ARG, "bad band size %d x %d", rows_local, cols);
-  if (!d_workspace || workspace_bytes < layout_of(rows_local, cols).total)
+  if (!d_workspace || workspace_bytes < layout_of(rows_local, cols, cols).total)
     return smrf_fail(SMRF_E_WORKSPACE, "springs band workspace too small");
-  const Band b = band_of(d_workspace, rows_local, cols, 0, 0);
-  SMRF_HIP_CHECK(hipMemsetAsync(d_workspace, 0, layout_of(rows_local, cols).total, (hipStream_t)stream));
+  const Band b = band_of(d_workspace, rows_local, cols, cols, 0, 0);
+  SMRF_HIP_CHECK(hipMemsetAsync(d_workspace, 0, layout_of(rows_local, cols, cols).total, (hipStream_t)stream));
   return init_scalars(b, atol, btol, conlim, iter_lim, (hipStream_t)stream);
 }
 
 int smrf_springs_band_phase(int phase, double* d_A_band, int rows_local, int cols, int has_above, int has_below,
                             void* d_workspace, size_t workspace_bytes, void* stream) {
   if (!d_A_band || rows_local < 1 || cols < 1) return smrf_fail(SMRF_E_ARG, "bad band");
-  if (!d_workspace || workspace_bytes < layout_of(rows_local, cols).total)
+  if (!d_workspace || workspace_bytes < layout_of(rows_local, cols, cols).total)
     return smrf_fail(SMRF_E_WORKSPACE, "springs band workspace too small");
-  const Band b = band_of(d_workspace, rows_local, cols, has_above != 0, has_below != 0);
+  const Band b = band_of(d_workspace, rows_local, cols, cols, has_above != 0, has_below != 0);
   return run_phase(phase, d_A_band, b, (hipStream_t)stream);
 }
 
 int smrf_springs_band_status(const void* d_workspace, int rows_local, int cols, int* h_istop, int64_t* h_itn,
                              int64_t* h_n_unknown, int* h_done, void* stream) {
   if (!d_workspace || !h_istop || !h_itn || !h_done) return smrf_fail(SMRF_E_ARG, "null pointer");
-  const Band b = band_of(const_cast<void*>(d_workspace), rows_local, cols, 0, 0);
+  const Band b = band_of(const_cast<void*>(d_workspace), rows_local, cols, cols, 0, 0);
   Sc out{};
   SMRF_HIP_CHECK(hipMemcpyAsync(&out, b.sc, sizeof(out), hipMemcpyDeviceToHost, (hipStream_t)stream));
   SMRF_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
