@@ -25,7 +25,7 @@
  *   smrf_pssm_f64             pssm(), neilpy/neilpy.py:846-867
  *   smrf_las_decode_xyz_f64   the coordinate decode of read_las(), neilpy/neilpy.py:903-1087 (host
  *                             side: neilpy_amd/las.py)
- *   smrf_spline_solve_f64, smrf_spline_eval_f64, smrf_classify_points_f64
+ *   smrf_spline_solve_f64, smrf_spline_solve_ws_f64, smrf_spline_eval_f64, smrf_classify_points_f64
  *                             RectBivariateSpline(...).ev and the point test, neilpy/neilpy.py:1768-1795
  *   smrf_negate_f64, smrf_mask_apply_f64
  *                             the elementwise glue of smrf(), neilpy/neilpy.py:1744, :1748, :1762-1763
@@ -276,6 +276,12 @@ SMRF_API int smrf_pssm_f64(const double* d_Z, uint8_t* d_P, double* d_rgba, cons
  * doubles: l2, l1, d, u1, u2) of the per-axis collocation systems; neilpy_amd/spline.py builds them. */
 SMRF_API int smrf_spline_solve_f64(double* d_C, int rows, int cols, const double* d_lu_rows,
                           const double* d_lu_cols, void* stream);
+/* The same solve with a scratch plane of rows x cols doubles, which lets every line be cut into chunks that run side by
+ * side (each chunk re-derives its start state from 64 entries of warm-up; the substitutions contract by 0.268 per entry,
+ * so nothing of the cut is left in float64).  d_C: raster in, coefficients out; d_scratch: clobbered.  This is the entry
+ * neilpy_amd.smrf uses; the one above is the line-by-line sequential form the tests compare it with. */
+SMRF_API int smrf_spline_solve_ws_f64(double* d_C, double* d_scratch, int rows, int cols, const double* d_lu_rows,
+                             const double* d_lu_cols, void* stream);
 /* .ev(px, py) of that spline (FITPACK bispeu): px runs along the rows axis, py along the columns
  * axis; d_tx (rows + 4) and d_ty (cols + 4) are the knots; arguments are clamped to the knot range. */
 SMRF_API int smrf_spline_eval_f64(const double* d_C, int rows, int cols, const double* d_tx, const double* d_ty,

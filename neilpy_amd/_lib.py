@@ -64,6 +64,7 @@ SIGNATURES = {
     "smrf_gradient_slope_f64": (_i, [_p, _p, _i, _i, _d, _p]),
     "smrf_pssm_f64": (_i, [_p, _p, _p, _p, _i, _i, _d, _d, _p]),
     "smrf_spline_solve_f64": (_i, [_p, _i, _i, _p, _p, _p]),
+    "smrf_spline_solve_ws_f64": (_i, [_p, _p, _i, _i, _p, _p, _p]),
     "smrf_spline_eval_f64": (_i, [_p, _i, _i, _p, _p, _p, _p, _i64, _p, _p]),
     "smrf_classify_points_f64": (_i, [_p, _p, _p, _i64, _d, _d, _p, _p]),
     "smrf_negate_f64": (_i, [_p, _p, _i64, _p]),

@@ -402,9 +402,10 @@ def _classify_points_device(Zpro_d, t, cellsize, xd, yd, zd, elevation_threshold
     lur_d, luc_d = torch.from_numpy(lur).to(Zpro_d.device), torch.from_numpy(luc).to(Zpro_d.device)
     npts = xd.numel()
     vals = []
+    scratch = torch.empty_like(Zpro_d)
     for plane in (Zpro_d, S_d):
         coef = plane.clone()
-        _lib.check(lib.smrf_spline_solve_f64(_ptr(coef), rows, cols, _ptr(lur_d), _ptr(luc_d), _stream()))
+        _lib.check(lib.smrf_spline_solve_ws_f64(_ptr(coef), _ptr(scratch), rows, cols, _ptr(lur_d), _ptr(luc_d), _stream()))
         out = torch.empty(npts, dtype=torch.float64, device=Zpro_d.device)
         _lib.check(lib.smrf_spline_eval_f64(_ptr(coef), rows, cols, _ptr(tx_d), _ptr(ty_d), _ptr(r_d), _ptr(c_d), npts,
                                             _ptr(out), _stream()))

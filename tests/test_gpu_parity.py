@@ -387,6 +387,35 @@ def test_spline_matches_scipy(nz, gpu_device):
     assert rc == -1                                       # fewer than 4 sites: refused like SciPy refuses
 
 
+def test_chunked_spline_solve_equals_the_sequential_one(nz, gpu_device):
+    """smrf_spline_solve_ws_f64 (lines cut into chunks with a 64-entry warm-up, what smrf() uses) against the line-by-line
+    smrf_spline_solve_f64: rasters large enough for several chunks per axis, rough data; the cut leaves 0.268^64 of the
+    unknown state, so the two agree to rounding (and to SciPy's coefficients within the same 1e-10 as the sequential form)."""
+    import ctypes as C
+    import torch
+    from scipy import interpolate
+    from neilpy_amd import _lib, spline
+    lib = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    rng = np.random.default_rng(5)
+    for rows, cols in ((4, 4), (9, 300), (700, 513), (2100, 1500)):
+        Z = rng.normal(100, 30, (rows, cols)) + rng.choice([0.0, 500.0], (rows, cols), p=[.97, .03])
+        lur, luc = spline.axis_factors(rows)[1], spline.axis_factors(cols)[1]
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu_device)
+        lurd, lucd = dev(lur), dev(luc)
+        seq, chk, scratch = dev(Z), dev(Z), torch.full((rows, cols), float("nan"), dtype=torch.float64, device=gpu_device)
+        _lib.check(lib.smrf_spline_solve_f64(p(seq), rows, cols, p(lurd), p(lucd), st))
+        _lib.check(lib.smrf_spline_solve_ws_f64(p(chk), p(scratch), rows, cols, p(lurd), p(lucd), st))
+        a, b = seq.cpu().numpy(), chk.cpu().numpy()
+        assert np.isfinite(b).all()
+        assert np.abs(a - b).max() <= 1e-12 * np.abs(a).max(), (rows, cols, np.abs(a - b).max())
+        if rows * cols <= 400_000:
+            f = interpolate.RectBivariateSpline(np.arange(.5, rows + .5), np.arange(.5, cols + .5), Z)
+            np.testing.assert_allclose(b.ravel(), f.tck[2], rtol=0, atol=1e-9)
+    assert lib.smrf_spline_solve_ws_f64(p(chk), p(scratch), 3, 9, p(lurd), p(lucd), st) == -1
+
+
 def test_smrf_pandas_series_in(nz):
     import pandas as pd
     x, y, z, g = load_sample("samp24")
