@@ -3,7 +3,8 @@
 ``torch.from_numpy(a).cuda()`` / ``t.cpu()`` on pageable memory run at 2-3 GB/s on the GPU boxes;
 staging the same bytes through pinned memory in 16 MB chunks overlaps the host memcpy of one chunk with
 the DMA of another.  One thread's memcpy moves about 10 GB/s - less than the link - so the memcpys of up to
-three chunks run side by side on a small worker pool (NumPy releases the GIL in a contiguous copy; the workers
+five chunks run side by side on a small worker pool (1.6 GB array on a GPU box: 22 -> 51 GB/s up, 8 -> 16 GB/s down, where
+the fresh pages of the NumPy result are the limit; gpurun_out/r02/xfer_probe.log) (NumPy releases the GIL in a contiguous copy; the workers
 touch host memory only, every HIP call stays on the caller's thread).  Small arrays take the direct path.
 The drop-in functions use this at their NumPy boundary (points in, rasters out); everything between
 stays in HBM.
@@ -15,7 +16,7 @@ import numpy as np
 
 STAGE_BYTES = 16 << 20
 SMALL = 4 << 20
-NBUF = 4                # staging buffers per (thread, device): one or two under DMA, the others being filled / drained
+NBUF = 6                # staging buffers per (thread, device): one or two under DMA, the others being filled / drained
 _tls = threading.local()
 _pool = None
 _pool_lock = threading.Lock()
@@ -27,7 +28,7 @@ def _workers():
         with _pool_lock:
             if _pool is None:
                 from concurrent.futures import ThreadPoolExecutor
-                _pool = ThreadPoolExecutor(max_workers=3, thread_name_prefix="neilpy_amd_xfer")
+                _pool = ThreadPoolExecutor(max_workers=NBUF - 1, thread_name_prefix="neilpy_amd_xfer")
     return _pool
 
 
