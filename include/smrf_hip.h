@@ -216,8 +216,9 @@ SMRF_API int smrf_springs_lsqr_f64(double* d_A, int rows, int cols, double atol,
  * holds rows_local x cols cells of d_A_band.  The workspace keeps every plane with one halo row
  * above and one below; smrf_springs_band_layout() gives the byte offsets the host needs to
  * exchange halo rows and to all-reduce the phase sums:
- *   h_out[0] v plane, h_out[1] uv plane (rows_local + 2 rows of cols doubles, row 0 = halo above),
- *   h_out[2] hole plane (rows_local + 2 rows of cols bytes), h_out[3] cols doubles = raster row
+ *   h_out[0] v plane, h_out[1] uv plane (rows_local + 2 rows, h_out[6] doubles apart, the first cols used; row 0 = halo above),
+ *   h_out[2] hole plane (rows_local + 2 rows, h_out[6] bytes apart), h_out[6] the planes' row pitch in cells (>= cols),
+ *   h_out[3] cols doubles = raster row
  *   below the band, h_out[4] two doubles = the phase's local sums (phase 3 fills both: |v|^2 and |w|^2,
  *   to be all-reduced as ONE 2-element buffer; every other phase uses the first), h_out[5] total bytes.
  * Phases (in order; "<- X" = what the host must have delivered before the phase):

@@ -295,8 +295,8 @@ struct Layout {
 // 16385 columns; on 32769 columns (1.07e9 cells, 8.6 GB per plane) a 4 KB pitch is worth 11 % (26.6 -> 23.6 ms per iteration
 // against 22.3 ms on 32768 columns) while it costs 5-9 % at 8193 and 16385 (gpurun_out/r02/lsqr_pitch3.log, lsqr_pitch4.log),
 // hence the size rule.  Pad cells are never touched; every thread walks the same cells in the same order as without padding, so
-// all sums, the stop iteration and the result are bit-identical.  The band form keeps ld = cols: its halo rows are addressed by
-// the host (neilpy_amd/sharded.py) through smrf_springs_band_layout.
+// all sums, the stop iteration and the result are bit-identical.  The band form uses the same pitch; the host
+// (neilpy_amd/sharded.py) addresses its halo rows through smrf_springs_band_layout, which reports it.
 long long padded_pitch(int cols) {
   const long long a = cols >= 24576 ? 512 : 32;
   return (((long long)cols + a - 1) / a) * a;
@@ -453,43 +453,44 @@ int smrf_springs_lsqr_f64(double* d_A, int rows, int cols, double atol, double b
   return SMRF_OK;
 }
 
-size_t smrf_springs_band_workspace_bytes(int rows_local, int cols) { return layout_of(rows_local, cols, cols).total; }
+size_t smrf_springs_band_workspace_bytes(int rows_local, int cols) { return layout_of(rows_local, cols, padded_pitch(cols)).total; }
 
 int smrf_springs_band_layout(int rows_local, int cols, int64_t* h_out) {
   if (!h_out || rows_local < 1 || cols < 1) return smrf_fail(SMRF_E_ARG, "bad band");
-  const Layout L = layout_of(rows_local, cols, cols);
-  h_out[0] = (int64_t)L.v;       // v plane    (rows_local + 2 rows of cols doubles, row 0 = halo above)
+  const Layout L = layout_of(rows_local, cols, padded_pitch(cols));
+  h_out[0] = (int64_t)L.v;       // v plane    (rows_local + 2 rows, h_out[6] doubles apart, cols of them used; row 0 = halo above)
   h_out[1] = (int64_t)L.uv;      // uv plane   (same shape)
-  h_out[2] = (int64_t)L.hole;    // hole plane (rows_local + 2 rows of cols bytes)
+  h_out[2] = (int64_t)L.hole;    // hole plane (rows_local + 2 rows, h_out[6] bytes apart)
   h_out[3] = (int64_t)L.abelow;  // cols doubles: the raster row below the band
   h_out[4] = (int64_t)L.red;     // 2 doubles: the phase sums to all-reduce (PH_ATU uses both, the others the first)
   h_out[5] = (int64_t)L.total;
+  h_out[6] = (int64_t)padded_pitch(cols);   // cells between the rows of every plane (>= cols)
   return SMRF_OK;
 }
 
 int smrf_springs_band_begin(int rows_local, int cols, double atol, double btol, double conlim, int64_t iter_lim,
                             void* d_workspace, size_t workspace_bytes, void* stream) {
   if (rows_local < 1 || cols < 1) return smrf_fail(SMRF_E_ARG, "bad band size %d x %d", rows_local, cols);
-  if (!d_workspace || workspace_bytes < layout_of(rows_local, cols, cols).total)
+  if (!d_workspace || workspace_bytes < layout_of(rows_local, cols, padded_pitch(cols)).total)
     return smrf_fail(SMRF_E_WORKSPACE, "springs band workspace too small");
-  const Band b = band_of(d_workspace, rows_local, cols, cols, 0, 0);
-  SMRF_HIP_CHECK(hipMemsetAsync(d_workspace, 0, layout_of(rows_local, cols, cols).total, (hipStream_t)stream));
+  const Band b = band_of(d_workspace, rows_local, cols, padded_pitch(cols), 0, 0);
+  SMRF_HIP_CHECK(hipMemsetAsync(d_workspace, 0, layout_of(rows_local, cols, padded_pitch(cols)).total, (hipStream_t)stream));
   return init_scalars(b, atol, btol, conlim, iter_lim, (hipStream_t)stream);
 }
 
 int smrf_springs_band_phase(int phase, double* d_A_band, int rows_local, int cols, int has_above, int has_below,
                             void* d_workspace, size_t workspace_bytes, void* stream) {
   if (!d_A_band || rows_local < 1 || cols < 1) return smrf_fail(SMRF_E_ARG, "bad band");
-  if (!d_workspace || workspace_bytes < layout_of(rows_local, cols, cols).total)
+  if (!d_workspace || workspace_bytes < layout_of(rows_local, cols, padded_pitch(cols)).total)
     return smrf_fail(SMRF_E_WORKSPACE, "springs band workspace too small");
-  const Band b = band_of(d_workspace, rows_local, cols, cols, has_above != 0, has_below != 0);
+  const Band b = band_of(d_workspace, rows_local, cols, padded_pitch(cols), has_above != 0, has_below != 0);
   return run_phase(phase, d_A_band, b, (hipStream_t)stream);
 }
 
 int smrf_springs_band_status(const void* d_workspace, int rows_local, int cols, int* h_istop, int64_t* h_itn,
                              int64_t* h_n_unknown, int* h_done, void* stream) {
   if (!d_workspace || !h_istop || !h_itn || !h_done) return smrf_fail(SMRF_E_ARG, "null pointer");
-  const Band b = band_of(const_cast<void*>(d_workspace), rows_local, cols, cols, 0, 0);
+  const Band b = band_of(const_cast<void*>(d_workspace), rows_local, cols, padded_pitch(cols), 0, 0);
   Sc out{};
   SMRF_HIP_CHECK(hipMemcpyAsync(&out, b.sc, sizeof(out), hipMemcpyDeviceToHost, (hipStream_t)stream));
   SMRF_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));

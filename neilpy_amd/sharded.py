@@ -322,10 +322,11 @@ class HipSpringsOps:
         self.ws = torch.empty(self.nbytes, dtype=torch.uint8, device=A_band.device)
         lay = (C.c_int64 * 8)()
         _lib.check(self.lib.smrf_springs_band_layout(self.rows, self.cols, lay))
-        n2 = (self.rows + 2) * self.cols
-        self.v = self.ws[lay[0]:lay[0] + n2 * 8].view(torch.float64).view(self.rows + 2, self.cols)
-        self.uv = self.ws[lay[1]:lay[1] + n2 * 8].view(torch.float64).view(self.rows + 2, self.cols)
-        self.hole = self.ws[lay[2]:lay[2] + n2].view(self.rows + 2, self.cols)
+        ld = int(lay[6])                                      # cells between plane rows (>= cols: padded to cache lines)
+        n2 = (self.rows + 2) * ld
+        self.v = self.ws[lay[0]:lay[0] + n2 * 8].view(torch.float64).view(self.rows + 2, ld)[:, :self.cols]
+        self.uv = self.ws[lay[1]:lay[1] + n2 * 8].view(torch.float64).view(self.rows + 2, ld)[:, :self.cols]
+        self.hole = self.ws[lay[2]:lay[2] + n2].view(self.rows + 2, ld)[:, :self.cols]
         self.abelow = self.ws[lay[3]:lay[3] + self.cols * 8].view(torch.float64)
         self.red2 = self.ws[lay[4]:lay[4] + 16].view(torch.float64)      # [|v|^2, |w|^2] of the ATU phase
         self.red = self.red2[:1]                                          # the single sum of the other phases
