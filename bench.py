@@ -31,8 +31,8 @@ sys.path.insert(0, ROOT)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", dest="n", type=int, default=16384, help="DEM is size x size cells")
     ap.add_argument("--windows", type=int, default=50, help="radii 1..windows")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
