@@ -83,6 +83,10 @@ def load():
         raise SmrfHipError(
             "libsmrf_hip.so is not built (%s missing). Run `python -m neilpy_amd.build`; "
             "neilpy_amd has no CPU fallback." % LIB_PATH)
+    # torch first: its wheel carries its own libamdhip64 (same SONAME as /opt/rocm's, other file name).  Loaded after
+    # this library it would be a SECOND HIP runtime in the process, and the one that initialises last sees no device
+    # (`python __graft_entry__.py smoke`: build() loads the library before anything imports torch).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     override = bool(os.environ.get("NEILPY_AMD_LIB"))
     for name, (res, args) in SIGNATURES.items():
