@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--cpu-crop", type=int, default=192, help="crop edge for the CPU baseline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not collect roofline.traffic live (two rocprofv3 --pmc child "
+                    "runs, ~1 min); quote profiles/pmc_summary.json instead")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo stages halos through the host: for rehearsing N>1 ranks on one GPU")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal on a one-GPU box)")
@@ -63,6 +65,45 @@ def cpu_baseline(Z_crop, windows, cellsize, slope):
     except Exception as e:  # noqa: BLE001  (the single-thread figure above is the baseline; this one is extra)
         out["all_cores"] = {"error": repr(e)[:200]}
     return out
+
+
+def pmc_traffic_live(n, windows, dtype, timeout_s=150):
+    """HBM bytes per pass of this workload from the hardware counters, measured now: two child runs of
+    tools/pmc_traffic.py (one progressive_filter step + a calibration read) under ``rocprofv3 --pmc FETCH_SIZE`` and
+    ``--pmc WRITE_SIZE`` - separate passes, --kernel-trace only, as MI355X_MICROARCH's HBM section prescribes - reduced
+    by tools/profile_summary.pmc (reads scaled by the calibration kernel's known byte count).  None when rocprofv3
+    is not there, a pass fails or times out: the caller then quotes the committed summary instead."""
+    import glob
+    import importlib.util
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None or dtype != "f32":
+        return None
+    spec = importlib.util.spec_from_file_location("profile_summary", os.path.join(ROOT, "tools", "profile_summary.py"))
+    ps = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ps)
+    tmp = tempfile.mkdtemp(prefix="smrf_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    csvs = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+                                sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), "--size", str(n),
+                                "--windows", str(windows)], cwd="/tmp", env=env, capture_output=True, text=True,
+                               timeout=timeout_s)
+            found = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not found:
+                return None
+            csvs[counter] = found[0]
+        rec = ps.pmc(csvs["FETCH_SIZE"], csvs["WRITE_SIZE"], n, windows, None)
+        return rec if rec.get("fetch_calibration") else None
+    except Exception:  # noqa: BLE001  (a measurement aid: never fail the bench line over it)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
@@ -177,7 +218,19 @@ def main():
         # summary of the same workload is quoted and labelled as such (tools/profile_round.sh regenerates it)
         traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):
+        live = None
+        if world == 1 and not a.no_pmc:
+            # the timed region is over: release this process's planes first, the child runs need the same HBM
+            del mask
+            Z = None
+            torch.cuda.empty_cache()
+            live = pmc_traffic_live(n, a.windows, a.dtype)
+        if live is not None:
+            traffic = live["hbm_bytes_per_launch"]
+            traffic_source = ("live: two child runs of tools/pmc_traffic.py under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
+                              "(--kernel-trace only), reads x%.3f (calibration kernel of known size), per pass"
+                              % live["fetch_calibration"])
+        elif os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
                 if rec.get("n") == n and rec.get("windows") == a.windows and rec.get("dtype") == a.dtype and world == 1:

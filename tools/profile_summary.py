@@ -79,8 +79,10 @@ def pmc(fetch_csv, write_csv, n, windows, out):
                fetch_bytes_corrected=ring_f * scale if scale else None,
                hbm_bytes_per_launch=((ring_f * scale if scale else ring_f) + ring_w) / max(launches, 1),
                algorithmic_bytes_per_launch=n * n * 11.0)
-    json.dump(rec, open(out, "w"), indent=1)
-    print(json.dumps(rec, indent=1))
+    if out:
+        json.dump(rec, open(out, "w"), indent=1)
+        print(json.dumps(rec, indent=1))
+    return rec
 
 
 if __name__ == "__main__":
