@@ -72,6 +72,11 @@
 #ifndef SMRF_RING_OCC_DROP
 #define SMRF_RING_OCC_DROP 0   // tuning builds: run every radius one occupancy step below the estimate
 #endif
+// the 2R halo cells of a staged row (beyond the 256 under the lanes) shared out over all waves of the workgroup,
+// row pair by row pair, instead of all of them falling to the first waves (ring_kernel, HaloCfg)
+#ifndef SMRF_RING_BAL
+#define SMRF_RING_BAL 1
+#endif
 #ifndef SMRF_FORCE_OCC
 #define SMRF_OCC_OVERRIDE(...) __VA_ARGS__
 #else
@@ -87,6 +92,7 @@ constexpr int ring_occ_drop(int occ, int steps) {
 }
 
 #include "ring_tune.inc"
+#include "ring_bal.inc"
 
 // columns per workgroup per radius: 256 everywhere (512-column workgroups, one per CU, measured within +-1 % of 256 at
 // R >= 39 and 20-25 % slower below: gpurun_out/r02/probe_tw512.log)
@@ -442,6 +448,120 @@ __device__ __forceinline__ void ring_upper(typename Vec2<T>::type* const L, cons
   }
 }
 
+// ---- the halo cells of a batch, shared out over the waves (ring_kernel) -------------------------------------------
+// A staged row is TW + 2R cells wide.  With one cell per lane plus "cell TW + tid if there is one", the 2R halo cells of
+// EVERY row pair fall to the first one or two waves, which then build twice the table cells of the others and keep the
+// whole workgroup at each phase barrier.  Here the halo of a batch is cut into wave-jobs (row pair p, 64-cell part) and
+// wave w takes jobs w, w + WAVES, ...: with 4 row pairs and 2R <= 64 one job per wave, with 2R > 64 two.  A lane's halo
+// cell is the same in all its jobs (WAVES is a multiple of the parts per row), only the row pair changes.
+template <typename T, int R, int TW, int NP>
+struct HaloCfg {
+  using C = RingCfg<T, R, TW, NP>;
+  static constexpr int HW = C::W - TW;                   // halo cells per row
+  static constexpr int WAVES = TW / 64;
+  static constexpr int NH = (HW + 63) / 64;              // 64-cell parts per row
+  static constexpr int NQ = NP * NH;                     // wave-jobs per batch
+  static constexpr int NJ = (NQ + WAVES - 1) / WAVES;    // most jobs one wave takes
+  static constexpr bool OK = SMRF_RING_BAL && ring_tuned_bal<T>(R) && C::NPOS == 2 && TW % 64 == 0 && WAVES >= 2 && WAVES % NH == 0;
+};
+struct HaloLane {
+  int wave;      // wave index in the workgroup (uniform)
+  bool act;      // this lane has a halo cell
+  int pos;       // its staged cell (TW + h), or a cell that is safe to read when it has none
+};
+
+template <typename T, int R, bool DIL, int TW, int NP>
+__device__ __forceinline__ void ring_base_halo(typename Vec2<T>::type* const L, const int par, const HaloLane hl,
+                                               typename Vec2<T>::type (&vh)[HaloCfg<T, R, TW, NP>::NJ]) {
+  using C = RingCfg<T, R, TW, NP>;
+  using H = HaloCfg<T, R, TW, NP>;
+  using T2 = typename Vec2<T>::type;
+  constexpr int WP = C::WP, NLEV = C::NLEV, JB = C::JB, SB = C::slot_of(JB);
+  constexpr int NA = (1 << JB) - 1;
+  const unsigned lds_h = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(L + hl.pos);
+  if (hl.act) {
+    T2 na[H::NJ][NA];
+#pragma unroll
+    for (int j = 0; j < H::NJ; ++j) {
+      const int q = hl.wave + H::WAVES * j;
+      if (q < H::NQ) {
+        const unsigned ad = lds_h + (unsigned)(((q / H::NH) * NLEV + par) * WP) * (unsigned)sizeof(T2);
+        [&]<int... Kk>(std::integer_sequence<int, Kk...>) {
+          ((na[j][Kk] = lds_read2<(Kk + 1) * (int)sizeof(T2)>(ad, T())), ...);
+        }(std::make_integer_sequence<int, NA>{});
+      }
+    }
+    lds_wait<0>();
+#pragma unroll
+    for (int j = 0; j < H::NJ; ++j) {
+      const int q = hl.wave + H::WAVES * j;
+      if (q < H::NQ) {
+        const T2* n = na[j];
+        T2 m = vh[j];
+        if constexpr (JB == 1) { m.x = op2<DIL>(m.x, n[0].x); m.y = op2<DIL>(m.y, n[0].y); }
+        if constexpr (JB >= 2) {
+          m.x = op3<DIL>(m.x, n[0].x, n[1].x); m.y = op3<DIL>(m.y, n[0].y, n[1].y);
+          m.x = op2<DIL>(m.x, n[2].x); m.y = op2<DIL>(m.y, n[2].y);
+        }
+        if constexpr (JB == 3) {
+          m.x = op3<DIL>(m.x, n[3].x, n[4].x); m.y = op3<DIL>(m.y, n[3].y, n[4].y);
+          m.x = op3<DIL>(m.x, n[5].x, n[6].x); m.y = op3<DIL>(m.y, n[5].y, n[6].y);
+        }
+        vh[j] = m;
+        L[((q / H::NH) * NLEV + SB) * WP + hl.pos] = m;
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <typename T, int R, bool DIL, int TW, int NP>
+__device__ __forceinline__ void ring_upper_halo(typename Vec2<T>::type* const L, const HaloLane hl,
+                                                typename Vec2<T>::type (&vh)[HaloCfg<T, R, TW, NP>::NJ]) {
+  using C = RingCfg<T, R, TW, NP>;
+  using H = HaloCfg<T, R, TW, NP>;
+  using T2 = typename Vec2<T>::type;
+  constexpr int J = C::J, WP = C::WP, NLEV = C::NLEV, JB = C::JB, SB = C::slot_of(JB);
+  if constexpr (J > JB) {
+    constexpr int NB = (1 << (J - JB)) - 1;
+    const unsigned lds_h = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(L + hl.pos);
+    if (hl.act) {
+#pragma unroll
+      for (int j = 0; j < H::NJ; ++j) {
+        const int q = hl.wave + H::WAVES * j;
+        if (q < H::NQ) {
+          const int pq = q / H::NH;
+          const unsigned ad = lds_h + (unsigned)((pq * NLEV + SB) * WP) * (unsigned)sizeof(T2);
+          T2 nb[NB];
+          [&]<int... Kk>(std::integer_sequence<int, Kk...>) {
+            ((nb[Kk] = lds_read2<((Kk + 1) << JB) * (int)sizeof(T2)>(ad, T())), ...);
+          }(std::make_integer_sequence<int, NB>{});
+          lds_wait<0>();
+          T2 m = vh[j];
+          [&]<int... JJ>(std::integer_sequence<int, JJ...>) {
+            (([&] {
+               constexpr int lv = JB + 1 + JJ;           // level being completed
+               constexpr int k0 = 1 << (lv - 1 - JB);    // new cells k0 .. 2*k0 - 1
+               if constexpr (k0 == 1) { m.x = op2<DIL>(m.x, nb[0].x); m.y = op2<DIL>(m.y, nb[0].y); }
+               else {
+#pragma unroll
+                 for (int k = k0; k < 2 * k0; k += 2) {
+                   m.x = op3<DIL>(m.x, nb[k - 1].x, nb[k].x); m.y = op3<DIL>(m.y, nb[k - 1].y, nb[k].y);
+                 }
+               }
+               if constexpr (C::stored(lv)) {
+                 constexpr int sj = C::slot_of(lv);
+                 L[(pq * NLEV + sj) * WP + hl.pos] = m;
+               }
+             }()), ...);
+          }(std::make_integer_sequence<int, J - JB>{});
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 template <typename T, int R, bool DIL, int TW, int NP>
 __device__ __forceinline__ void ring_consume(typename Vec2<T>::type* const L, const int par, const int tid, T (&acc)[2 * R],
                                              T (&outv)[2 * NP]) {
@@ -593,6 +713,17 @@ void ring_kernel(const DiskArgs<T> a) {
 #pragma unroll
   for (int i = 0; i < NPOS; ++i) cpos[i] = smrf_fold(x0 - R + tid + (tid + i * TW < W ? i * TW : 0), a.cols);
   const int last_in = a.in_rows - 1;
+  // halo cells shared out over the waves (HaloCfg): this lane's halo cell and the column it is loaded from
+  using H = HaloCfg<T, R, TW, NP>;
+  constexpr bool BAL = H::OK;
+  HaloLane hl;
+  hl.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {
+    const int h = (hl.wave % H::NH) * 64 + (tid & 63);
+    hl.act = BAL && h < H::HW;
+    hl.pos = hl.act ? TW + h : TW;
+  }
+  const int hcol = smrf_fold(x0 - R + hl.pos, a.cols);
   // workgroup-wide when the table is shared by several waves; a single-wave workgroup owns its
   // table and only has to keep the compiler from moving LDS accesses across the phase boundary
   auto phase_sync = [&]() {
@@ -608,6 +739,7 @@ void ring_kernel(const DiskArgs<T> a) {
   for (int i = 0; i < 2 * R; ++i) acc[i] = ident<T>(DIL);
 
   T2 pf[NP][NPOS];                                       // next batch, this lane's staged cells
+  T2 pfh[H::NJ];                                         // BAL: next batch, this lane's halo cell of its wave's jobs
   T outv[ROWS], lastv[ROWS];
 #pragma unroll
   for (int i = 0; i < ROWS; ++i) { outv[i] = T(0); lastv[i] = T(0); }
@@ -625,9 +757,18 @@ void ring_kernel(const DiskArgs<T> a) {
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
 #pragma unroll
-        for (int i = 0; i < NPOS; ++i) {
+        for (int i = 0; i < (BAL ? 1 : NPOS); ++i) {
           pf[p][i].x = r0[(long long)(2 * p) * a.ld + cpos[i]];
           pf[p][i].y = r0[(long long)(2 * p + 1) * a.ld + cpos[i]];
+        }
+      }
+      if constexpr (BAL) {
+#pragma unroll
+        for (int j = 0; j < H::NJ; ++j) {
+          const int q = hl.wave + H::WAVES * j;            // wave-job: row pair q / NH (inactive lanes load a valid cell)
+          const int pq = q < H::NQ ? q / H::NH : 0;
+          pfh[j].x = r0[(long long)(2 * pq) * a.ld + hcol];
+          pfh[j].y = r0[(long long)(2 * pq + 1) * a.ld + hcol];
         }
       }
     } else {
@@ -640,7 +781,20 @@ void ring_kernel(const DiskArgs<T> a) {
         const T* ra = a.in + (long long)la * a.ld;
         const T* rb = a.in + (long long)lb * a.ld;
 #pragma unroll
-        for (int i = 0; i < NPOS; ++i) { pf[p][i].x = ra[cpos[i]]; pf[p][i].y = rb[cpos[i]]; }
+        for (int i = 0; i < (BAL ? 1 : NPOS); ++i) { pf[p][i].x = ra[cpos[i]]; pf[p][i].y = rb[cpos[i]]; }
+      }
+      if constexpr (BAL) {
+#pragma unroll
+        for (int j = 0; j < H::NJ; ++j) {
+          const int q = hl.wave + H::WAVES * j;
+          const int pq = q < H::NQ ? q / H::NH : 0;
+          int la = rf.at(2 * pq) - a.in_row0;
+          int lb = rf.at(2 * pq + 1) - a.in_row0;
+          la = la < 0 ? 0 : (la > last_in ? last_in : la);
+          lb = lb < 0 ? 0 : (lb > last_in ? last_in : lb);
+          pfh[j].x = a.in[(long long)la * a.ld + hcol];
+          pfh[j].y = a.in[(long long)lb * a.ld + hcol];
+        }
       }
     }
     rf.advance(ROWS);
@@ -701,13 +855,23 @@ void ring_kernel(const DiskArgs<T> a) {
     //     read by a slower wave (its own cells of the previous batch); the higher levels are only
     //     written after the barrier below, which every wave reaches after its previous consume.
     T2 v[NP][NPOS];
+    T2 vh[H::NJ];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
 #pragma unroll
-      for (int i = 0; i < NPOS; ++i) {
+      for (int i = 0; i < (BAL ? 1 : NPOS); ++i) {
         v[p][i] = pf[p][i];
         if (i < NPOS - 1 || has_last)
           lds_write2((unsigned)(size_t)(__attribute__((address_space(3))) void*)(L + (p * NLEV + par) * WP + tid + i * TW), v[p][i]);
+      }
+    }
+    if constexpr (BAL) {
+#pragma unroll
+      for (int j = 0; j < H::NJ; ++j) {
+        vh[j] = pfh[j];
+        const int q = hl.wave + H::WAVES * j;
+        if (hl.act && q < H::NQ)
+          lds_write2((unsigned)(size_t)(__attribute__((address_space(3))) void*)(L + ((q / H::NH) * NLEV + par) * WP + hl.pos), vh[j]);
       }
     }
     lds_wait<0>();                                         // the compiler does not count asm stores: complete them before the barrier
@@ -716,7 +880,23 @@ void ring_kernel(const DiskArgs<T> a) {
     if (yy0 + ROWS < ye + R) prefetch();
     load_last(yy0);
 
-    ring_build_consume<T, R, DIL, TW, NP, NPOS, 0>(L, par, tid, has_last, v, acc, outv, phase_sync);
+    if constexpr (BAL) {
+      // ring_build_consume with the halo cells as wave-jobs: every wave builds its own 256 cells' worth of each row
+      // pair plus its share of the halo, so the waves reach the phase barriers together
+      __builtin_amdgcn_s_setprio(SMRF_RING_BUILD_PRIO);
+      ring_base<T, R, DIL, TW, NP, 1, 0>(L, par, tid, true, v);
+      ring_base_halo<T, R, DIL, TW, NP>(L, par, hl, vh);
+      phase_sync();
+      if constexpr (C::J > C::JB) {
+        ring_upper<T, R, DIL, TW, NP, 1, 0>(L, tid, true, v);
+        ring_upper_halo<T, R, DIL, TW, NP>(L, hl, vh);
+        phase_sync();
+      }
+      __builtin_amdgcn_s_setprio(0);
+      ring_consume<T, R, DIL, TW, NP>(L, par, tid, acc, outv);
+    } else {
+      ring_build_consume<T, R, DIL, TW, NP, NPOS, 0>(L, par, tid, has_last, v, acc, outv, phase_sync);
+    }
   }
   {
     const int nb = (ye + R - ystart + ROWS - 1) / ROWS;
