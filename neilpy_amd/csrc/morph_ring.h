@@ -72,6 +72,10 @@
 #ifndef SMRF_RING_OCC_DROP
 #define SMRF_RING_OCC_DROP 0   // tuning builds: run every radius one occupancy step below the estimate
 #endif
+// incremental window widths (RingCfg::INC): per radius from ring_inc.inc, or everywhere / nowhere in tuning builds
+#ifndef SMRF_RING_INC
+#define SMRF_RING_INC(T, R) ring_tuned_inc<T>(R)
+#endif
 // the 2R halo cells of a staged row (beyond the 256 under the lanes) shared out over all waves of the workgroup,
 // row pair by row pair, instead of all of them falling to the first waves (ring_kernel, HaloCfg)
 #ifndef SMRF_RING_BAL
@@ -93,6 +97,7 @@ constexpr int ring_occ_drop(int occ, int steps) {
 
 #include "ring_tune.inc"
 #include "ring_bal.inc"
+#include "ring_inc.inc"
 
 // columns per workgroup per radius: 256 everywhere (512-column workgroups, one per CU, measured within +-1 % of 256 at
 // R >= 39 and 20-25 % slower below: gpurun_out/r02/probe_tw512.log)
@@ -221,8 +226,32 @@ struct RingCfg {
       if (clog2(2 * S::wk(k) + 1) == S::J) ++n;
     return n;
   }
-  static constexpr bool DROP_TOP = S::J >= 3 && n_top() <= SMRF_RING_TOP3(T, R) && 2 * R + 1 <= 3 * (1 << (S::J - 1));
-  static constexpr int J = DROP_TOP ? S::J - 1 : S::J;
+  // INC: the disk's widths taken in ascending order, each window grown from the one before it:
+  //     H[w_k] = min3(H[w_k-1], T_j[x - w_k], T_j[x + w_k - 2^j + 1]),  2^j >= w_k - w_k-1  (H[w_0 = 0] = the cell)
+  // - one read per side of the smallest table level that spans the step (a read may reach back into the window it
+  // extends: min / max is idempotent), two per side where the step is longer than 8 cells (only the first width of
+  // a disk with R >= 41).  The same two reads and one instruction per width as a lookup in a full sparse table, but
+  // no level above 3 is ever read: the second build phase with its reads and its barrier is gone, a level costs
+  // 8 cells of padding instead of 64, and the table of a large disk holds 5 levels instead of 6.
+  static constexpr bool INC = R >= 9 && SMRF_RING_INC(T, R);
+  static constexpr int inc_lev(int k) {                  // table level of the reads for width index k >= 1
+    const int d = S::wk(k) - S::wk(k - 1);
+    int j = 0;
+    while ((1 << j) < d && j < 3) ++j;
+    return j;
+  }
+  static constexpr int inc_n(int k) {                    // reads per side
+    const int d = S::wk(k) - S::wk(k - 1), j = inc_lev(k);
+    return (d + (1 << j) - 1) >> j;
+  }
+  static constexpr int inc_jmax() {
+    int j = 1;
+    for (int k = 1; k < S::K; ++k)
+      if (inc_lev(k) > j) j = inc_lev(k);
+    return j;
+  }
+  static constexpr bool DROP_TOP = !INC && S::J >= 3 && n_top() <= SMRF_RING_TOP3(T, R) && 2 * R + 1 <= 3 * (1 << (S::J - 1));
+  static constexpr int J = INC ? inc_jmax() : DROP_TOP ? S::J - 1 : S::J;
   static constexpr int lev(int w) { const int j = clog2(2 * w + 1); return j > J ? J : j; }   // level a width is read at
   static constexpr int nreads(int w) { return clog2(2 * w + 1) > J ? 3 : 2; }
   static constexpr int W = TW + 2 * R;                   // staged cells per row
@@ -237,7 +266,7 @@ struct RingCfg {
   static constexpr bool used(int j) {
     if (j == 0) return true;
     for (int k = 1; k < S::K; ++k)
-      if (lev(S::wk(k)) == j) return true;
+      if ((INC ? inc_lev(k) : lev(S::wk(k))) == j) return true;
     return false;
   }
   static constexpr int jmin() {                          // lowest level >= 1 that a lookup reads
@@ -245,8 +274,11 @@ struct RingCfg {
       if (used(j)) return j;
     return J;
   }
-  static constexpr int JB = jmin() < 3 ? jmin() : 3;     // base level
-  static constexpr bool stored(int j) { return j == 0 || (j >= JB && j <= J && (j == JB || used(j))); }
+  static constexpr int JB = INC ? J : jmin() < 3 ? jmin() : 3;   // base level (INC: the only build phase makes every level)
+  static constexpr bool stored(int j) {
+    if (INC) return j == 0 || (j >= 1 && j <= J && (j == J || used(j)));
+    return j == 0 || (j >= JB && j <= J && (j == JB || used(j)));
+  }
   // storage index of a stored level; level 0 is double buffered (indices 0 and 1, alternating per
   // batch) so that staging the next batch never races with a slower wave still reading its cells
   static constexpr int slot_of(int j) {
@@ -265,7 +297,7 @@ struct RingCfg {
   static constexpr int D = SMRF_RING_DEPTH(NEED_BASE);   // lookup groups kept in flight
   static constexpr int greads(int g) {                   // LDS reads of lookup group g
     int n = 0;
-    for (int k = 1 + g * G; k < 1 + (g + 1) * G && k < S::K; ++k) n += nreads(S::wk(k));
+    for (int k = 1 + g * G; k < 1 + (g + 1) * G && k < S::K; ++k) n += INC ? 2 * inc_n(k) : nreads(S::wk(k));
     return n;
   }
   static constexpr int inflight_after(int g) {           // reads of groups g+1 .. g+D-1
@@ -363,6 +395,19 @@ __device__ __forceinline__ void ring_base(typename Vec2<T>::type* const L, const
       for (int p = 0; p < NP; ++p) {
         const T2* n = na[p];
         T2 m = v[p][i];
+        if constexpr (C::INC) {
+          // every level a width step reads, on the way up to level JB (the same instruction count)
+          m.x = op2<DIL>(m.x, n[0].x); m.y = op2<DIL>(m.y, n[0].y);
+          if constexpr (JB >= 2) {
+            if constexpr (C::stored(1)) { constexpr int s1 = C::slot_of(1); L[(p * NLEV + s1) * WP + pos] = m; }
+            m.x = op3<DIL>(m.x, n[1].x, n[2].x); m.y = op3<DIL>(m.y, n[1].y, n[2].y);
+          }
+          if constexpr (JB == 3) {
+            if constexpr (C::stored(2)) { constexpr int s2 = C::slot_of(2); L[(p * NLEV + s2) * WP + pos] = m; }
+            m.x = op3<DIL>(m.x, n[3].x, n[4].x); m.y = op3<DIL>(m.y, n[3].y, n[4].y);
+            m.x = op3<DIL>(m.x, n[5].x, n[6].x); m.y = op3<DIL>(m.y, n[5].y, n[6].y);
+          }
+        } else {
         if constexpr (JB == 1) { m.x = op2<DIL>(m.x, n[0].x); m.y = op2<DIL>(m.y, n[0].y); }
         if constexpr (JB >= 2) {
           m.x = op3<DIL>(m.x, n[0].x, n[1].x); m.y = op3<DIL>(m.y, n[0].y, n[1].y);
@@ -371,6 +416,7 @@ __device__ __forceinline__ void ring_base(typename Vec2<T>::type* const L, const
         if constexpr (JB == 3) {
           m.x = op3<DIL>(m.x, n[3].x, n[4].x); m.y = op3<DIL>(m.y, n[3].y, n[4].y);
           m.x = op3<DIL>(m.x, n[5].x, n[6].x); m.y = op3<DIL>(m.y, n[5].y, n[6].y);
+        }
         }
         v[p][i] = m;
         L[(p * NLEV + SB) * WP + pos] = m;
@@ -498,6 +544,19 @@ __device__ __forceinline__ void ring_base_halo(typename Vec2<T>::type* const L, 
       if (q < H::NQ) {
         const T2* n = na[j];
         T2 m = vh[j];
+        const int pq = q / H::NH;
+        if constexpr (C::INC) {
+          m.x = op2<DIL>(m.x, n[0].x); m.y = op2<DIL>(m.y, n[0].y);
+          if constexpr (JB >= 2) {
+            if constexpr (C::stored(1)) { constexpr int s1 = C::slot_of(1); L[(pq * NLEV + s1) * WP + hl.pos] = m; }
+            m.x = op3<DIL>(m.x, n[1].x, n[2].x); m.y = op3<DIL>(m.y, n[1].y, n[2].y);
+          }
+          if constexpr (JB == 3) {
+            if constexpr (C::stored(2)) { constexpr int s2 = C::slot_of(2); L[(pq * NLEV + s2) * WP + hl.pos] = m; }
+            m.x = op3<DIL>(m.x, n[3].x, n[4].x); m.y = op3<DIL>(m.y, n[3].y, n[4].y);
+            m.x = op3<DIL>(m.x, n[5].x, n[6].x); m.y = op3<DIL>(m.y, n[5].y, n[6].y);
+          }
+        } else {
         if constexpr (JB == 1) { m.x = op2<DIL>(m.x, n[0].x); m.y = op2<DIL>(m.y, n[0].y); }
         if constexpr (JB >= 2) {
           m.x = op3<DIL>(m.x, n[0].x, n[1].x); m.y = op3<DIL>(m.y, n[0].y, n[1].y);
@@ -507,8 +566,9 @@ __device__ __forceinline__ void ring_base_halo(typename Vec2<T>::type* const L, 
           m.x = op3<DIL>(m.x, n[3].x, n[4].x); m.y = op3<DIL>(m.y, n[3].y, n[4].y);
           m.x = op3<DIL>(m.x, n[5].x, n[6].x); m.y = op3<DIL>(m.y, n[5].y, n[6].y);
         }
+        }
         vh[j] = m;
-        L[((q / H::NH) * NLEV + SB) * WP + hl.pos] = m;
+        L[(pq * NLEV + SB) * WP + hl.pos] = m;
       }
     }
   }
@@ -587,12 +647,28 @@ __device__ __forceinline__ void ring_consume(typename Vec2<T>::type* const L, co
     // levels 1 and 2 are equal, 3 (= the build phases' level) gives the gain back.
     __builtin_amdgcn_s_setprio(SMRF_RING_LOOKUP_PRIO);
     T ra[K], rb[K];                                      // window results of row A / row B per width
-    T2 ta[D][G], tb[D][G], tc[D][G];                    // D lookup groups in flight (tc: third read of the widest widths)
+    T2 ta[D][G], tb[D][G], tc[D][G], td[D][G];          // D lookup groups in flight (tc: third read of the widest widths; INC: tc, td second read per side)
+    // INC reads level 0 as well: this batch's copy of it
+    // (addressed from the row's first staged cell: ds_read offsets are unsigned)
+    const unsigned q0 = q + (unsigned)par * (unsigned)(WP * sizeof(T2)) - (unsigned)(R * sizeof(T2));
     auto issue = [&]<int GI>(std::integral_constant<int, GI>) {
       [&]<int... I>(std::integer_sequence<int, I...>) {
         (([&] {
            constexpr int k = 1 + GI * G + I;
-           if constexpr (k < K) {
+           if constexpr (k < K && C::INC) {
+             constexpr int w = S::wk(k);
+             constexpr int j = C::inc_lev(k);
+             static_assert(C::stored(j), "step level not built");
+             static_assert(C::inc_n(k) <= 2, "width step longer than two table entries");
+             constexpr int base = j == 0 ? R : C::slot_of(j) * WP;
+             const unsigned qq = j == 0 ? q0 : q;
+             ta[GI % D][I] = lds_read2<(base - w) * (int)sizeof(T2)>(qq, T());
+             tb[GI % D][I] = lds_read2<(base + w - (1 << j) + 1) * (int)sizeof(T2)>(qq, T());
+             if constexpr (C::inc_n(k) == 2) {
+               tc[GI % D][I] = lds_read2<(base - w + (1 << j)) * (int)sizeof(T2)>(qq, T());
+               td[GI % D][I] = lds_read2<(base + w - (2 << j) + 1) * (int)sizeof(T2)>(qq, T());
+             }
+           } else if constexpr (k < K) {
              constexpr int w = S::wk(k);
              constexpr int j = C::lev(w);
              constexpr int base = C::slot_of(j) * WP;
@@ -609,7 +685,16 @@ __device__ __forceinline__ void ring_consume(typename Vec2<T>::type* const L, co
       [&]<int... I>(std::integer_sequence<int, I...>) {
         (([&] {
            constexpr int k = 1 + GI * G + I;
-           if constexpr (k < K) {
+           if constexpr (k < K && C::INC) {
+             T a = op3<DIL>(ra[k - 1], ta[GI % D][I].x, tb[GI % D][I].x);
+             T b = op3<DIL>(rb[k - 1], ta[GI % D][I].y, tb[GI % D][I].y);
+             if constexpr (C::inc_n(k) == 2) {
+               a = op3<DIL>(a, tc[GI % D][I].x, td[GI % D][I].x);
+               b = op3<DIL>(b, tc[GI % D][I].y, td[GI % D][I].y);
+             }
+             ra[k] = a;
+             rb[k] = b;
+           } else if constexpr (k < K) {
              if constexpr (C::nreads(S::wk(k)) == 3) {
                ra[k] = op3<DIL>(ta[GI % D][I].x, tc[GI % D][I].x, tb[GI % D][I].x);
                rb[k] = op3<DIL>(ta[GI % D][I].y, tc[GI % D][I].y, tb[GI % D][I].y);
