@@ -233,7 +233,7 @@ struct RingCfg {
   // a disk with R >= 41).  The same two reads and one instruction per width as a lookup in a full sparse table, but
   // no level above 3 is ever read: the second build phase with its reads and its barrier is gone, a level costs
   // 8 cells of padding instead of 64, and the table of a large disk holds 5 levels instead of 6.
-  static constexpr bool INC = R >= 9 && SMRF_RING_INC(T, R);
+  static constexpr bool INC = SMRF_RING_INC(T, R);
   static constexpr int inc_lev(int k) {                  // table level of the reads for width index k >= 1
     const int d = S::wk(k) - S::wk(k - 1);
     int j = 0;

@@ -8,8 +8,7 @@ Input: logs of ``tools/ring_probe.py --libs <build with "-DSMRF_RING_INC(T,R)=1"
     python tools/ring_inc_inc.py --f32 gpurun_out/s2/inc_all_erode.log gpurun_out/s2/inc_all_flag.log \\
                                  --f64 gpurun_out/s2/inc_f64all_erode.log gpurun_out/s2/inc_f64all_flag.log
 
-A radius is switched on when erosion + dilation/flag together are at least 0.7 % faster with it (radii >= 9 only: below,
-the steps between a disk's widths never exceed one cell more than the table-free reads cover).
+A radius is switched on when erosion + dilation/flag together are at least 0.7 % faster with it.
 """
 import argparse
 import os
@@ -32,10 +31,10 @@ def load(paths):
 def table(paths):
     cur, var = load(paths)
     on = [0] * 65
-    for r in range(9, 65):
+    for r in range(1, 65):
         if r in cur and r in var and var[r] < cur[r] * 0.993:
             on[r] = 1
-    rs = [r for r in cur if r >= 9]
+    rs = [r for r in cur if r >= 1]
     return on, sum(var[r] if on[r] else cur[r] for r in rs), sum(cur[r] for r in rs)
 
 
@@ -51,7 +50,7 @@ def main():
     t32, t64 = table(a.f32), table(a.f64)
     out = """// Per-radius switch of the incremental window widths of the ring kernels (morph_ring.h, RingCfg::INC), measured on
 // MI355X (tools/ring_probe.py, erosion + dilation/flag, both builds interleaved in one process) and written by
-// tools/ring_inc_inc.py.  Index = radius (0 unused).  fp32, radii 9..64 summed: %.1f -> %.1f ms; fp64 (8192^2): %.1f -> %.1f ms.
+// tools/ring_inc_inc.py.  Index = radius (0 unused).  fp32, all radii summed: %.1f -> %.1f ms; fp64 (8192^2): %.1f -> %.1f ms.
 // "-DSMRF_RING_INC(T,R)=0" / "=1" overrides it in tuning builds.
 inline constexpr unsigned char kRingIncF32[65] = {
     %s};
