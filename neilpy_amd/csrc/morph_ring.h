@@ -10,11 +10,17 @@
 //   - The two rows of a pair are interleaved per cell in LDS ({rowA[x], rowB[x]}), so one
 //     ds_read_b64 / ds_write_b64 serves both rows.  A batch is prefetched into registers one batch
 //     ahead with coalesced global loads; level 0 of the table is double buffered.
-//   - Per row a sparse table of power-of-two window minima is built in two stages of independent
-//     reads (base level from the staged row, higher levels from the base level), 3 barriers per batch.
-//   - Each lane looks up the K distinct window minima of disk(R) (K ~ 0.59 R + 1; two reads of one
-//     level each), in software-pipelined groups of G widths.  All table reads are inline asm
-//     ds_read_b64 with counted s_waitcnt: hipcc would fuse them into half-rate ds_read2_b64.
+//   - Per row a table of power-of-two window minima (level j = min over 2^j cells from the cell on).
+//     Where ring_inc.inc switches RingCfg::INC on (fp32: R = 8 and up) only levels 0..3 exist, built
+//     in ONE phase of 7 independent reads per cell, and the K distinct window minima of disk(R)
+//     (K ~ 0.59 R + 1) are taken in ascending order, each GROWN from the one before it with one read
+//     per side of the smallest level that spans the step: 2 barriers per batch.  Elsewhere the full
+//     sparse table (levels up to log2(2R+1), base level + higher levels in two build phases, 3
+//     barriers) and two reads of one level per width.  Either way two ds_read_b64 and one v_min3 /
+//     v_min per width and row, in software-pipelined groups of G widths; all table reads are inline
+//     asm ds_read_b64 with counted s_waitcnt: hipcc would fuse them into half-rate ds_read2_b64.
+//   - The 2R halo cells of a staged row are shared out over the four waves row pair by row pair
+//     (HaloCfg, ring_bal.inc) so that the waves reach the phase barriers together.
 //   - The 2R output rows a pair contributes to are 2R accumulators in REGISTERS: slot s belongs to
 //     output row y_in - R + s.  After a pair every slot moves down by two for free, because
 //         acc[s] = min3(acc[s+2], RA[k(R-s-2)], RB[k(R-s-1)])
