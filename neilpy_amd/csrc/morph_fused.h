@@ -27,8 +27,14 @@ namespace smrf {
 // measured per radius on the 16384^2 benchmark DEM (gpurun_out/r02/fused3_per_radius_f32.log).  Running the two
 // stages' phases side by side under three barriers per batch (second stage one batch behind) was measured too:
 // no faster at any radius, slower at most (fused2_per_radius_f32.log), so the stages simply follow each other.
+#ifndef SMRF_FUSED_NP_ALL
+#define SMRF_FUSED_NP_ALL 0     // tuning builds: this many row pairs per batch at every fp32 radius
+#endif
 template <typename T>
-constexpr int fused_np(int r) { return sizeof(T) == 4 ? ((r == 2 || r == 3 || r == 8 || r == 10) ? 1 : 2) : 1; }
+constexpr int fused_np(int r) {
+  if (SMRF_FUSED_NP_ALL && sizeof(T) == 4) return SMRF_FUSED_NP_ALL;
+  return sizeof(T) == 4 ? ((r == 2 || r == 3 || r == 8 || r == 10) ? 1 : 2) : 1;
+}
 
 // workgroups per CU the kernel is built for: what the two tables' LDS allows, at most 4 (128 registers per lane)
 template <typename T, int R, int TW, int NP>
