@@ -8,13 +8,28 @@ slope_threshold)`` (all windows: erosion + dilation + flagging per window, plus 
 scan and bool mask) over the synthetic DEM ``synth_dem(n, seed=20240)`` already resident in HBM.  With N > 1
 (launched by torch.distributed.run, one rank per GPU) the DEM's rows are split into N bands and
 groups of consecutive windows exchange their halo rows with the neighbouring ranks over RCCL
-(neilpy_amd/sharded.py): the problem size is fixed, so ``scaling`` is "strong".  Rank 0 prints ONE JSON line (see README / DESIGN.md).
+(neilpy_amd/sharded.py): the problem size is fixed, so ``scaling`` is "strong".  Rank 0 prints ONE JSON line.
 
-``roofline``: the ring-kernel launches (2 per window) dominate; ``achieved`` is their
-algorithmic bytes per launch (N*(5*4+2)/2 = 11 B/cell) divided by their average
-duration, measured with events on the launch stream around the timed region.
-``cpu_baseline``: the NumPy/SciPy oracle (the same scipy.ndimage primitive the reference
-reaches through skimage), single thread, on a bounded crop of the same DEM with the same windows.
+Timing: W warm-up steps, then K steps between barrier + synchronize on both sides (``ms_per_step_mean`` = that wall
+time / K, max over ranks); every step also sits between two events on the launch stream, ``step_ms`` = the K
+device times (max over ranks per step), ``ms_per_step`` their MEDIAN and ``value`` = cells / median.
+
+``roofline`` (dominant kernels: smrf::ring_kernel, two passes per window, and the fused small-disk launches):
+  achieved      algorithmic bytes per pass ((5s + 2) / 2 B/cell, a pass = half a window) / median device
+                time per pass; frac = achieved / 8 TB/s
+  traffic       HBM bytes per pass from the hardware counters (two rocprofv3 --pmc child runs after the timed region);
+                frac_traffic = traffic / time per pass / peak - the physical rate; it is below `frac` because the
+                fused launches move 10 B/cell per window where the convention credits 22
+  classes       one extra step through smrf_progressive_filter_timed_* (an event per window): windows grouped by how
+                they ran, each class priced at the bytes it really moves (fused 2s + 2, chain of k windows (2s + 2k) / k,
+                two-pass 5s + 2 B/cell/window), so no GB/s in this block can exceed the peak
+``secondary`` (N = 1, after the headline; SURVEY 8d's secondary metric): full device smrf() on 20 M synthetic points
+  (per-stage ms, points/s, LSQR ms and GB/s per iteration) and the fp64 progressive_filter 8192^2 windows 1..18 rate
+  (fp64 is the dtype the reference's smrf runs in, neilpy.py:1136).
+``cpu_baseline``: the NumPy/SciPy oracle (the same scipy.ndimage primitive the reference reaches through skimage),
+  single thread, on a bounded crop of the same DEM with the same windows.
+N > 1: ``per_rank`` carries every rank's compute_ms / exchange_ms (events around each halo exchange) / bytes sent;
+  the run refuses to start on a backend other than nccl (= RCCL) unless --backend gloo is given.
 """
 import argparse
 import json
@@ -40,6 +55,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not collect roofline.traffic live (two rocprofv3 --pmc child "
                     "runs, ~1 min); quote profiles/pmc_summary.json instead")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the smrf() / fp64 secondary block")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo stages halos through the host: for rehearsing N>1 ranks on one GPU")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal on a one-GPU box)")
@@ -106,12 +122,88 @@ def pmc_traffic_live(n, windows, dtype, timeout_s=150):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def window_classes(Z, windows, thresholds, cells, elem, peak):
+    """One more step with an event at every window boundary: device time per window and how each ran, grouped into
+    classes priced at the HBM bytes that class really moves per cell and window."""
+    from neilpy_amd import api, _lib
+    timing = {}
+    api._progressive_filter_device(Z, windows, thresholds, False, nan_aware=0, timing=timing)   # warm (first-call setup)
+    api._progressive_filter_device(Z, windows, thresholds, False, nan_aware=0, timing=timing)
+    ms, route = timing["window_ms"], timing["route"]
+    # chains: route = ROUTE_CHAIN + position; the time of a chain is recorded on its last window, members before it 0
+    classes = {}
+    i = 0
+    while i < len(ms):
+        r = int(route[i])
+        j, t = i + 1, float(ms[i])
+        if r >= _lib.ROUTE_CHAIN:
+            while j < len(ms) and int(route[j]) > _lib.ROUTE_CHAIN:
+                t += float(ms[j])
+                j += 1
+            k = j - i
+            name, bpw = "chain%d" % k, (2.0 * elem + 2.0 * k) / k
+        elif r == _lib.ROUTE_FUSED:
+            name, bpw = "fused", 2.0 * elem + 2.0
+        elif r == _lib.ROUTE_COPY:
+            name, bpw = "copy", 3.0 * elem + 2.0
+        else:
+            name, bpw = ("two_pass" if r == _lib.ROUTE_TWO_PASS else "direct"), 5.0 * elem + 2.0
+        c = classes.setdefault(name, {"windows": 0, "ms": 0.0, "bytes_per_cell_window": bpw, "radii": []})
+        c["windows"] += j - i
+        c["ms"] += t
+        c["radii"] += [int(w) for w in windows[i:j]]
+        i = j
+    for c in classes.values():
+        c["gbps"] = c["bytes_per_cell_window"] * c["windows"] * cells / (c["ms"] * 1e-3) / 1e9
+        c["frac"] = c["gbps"] / peak
+        c["ms"] = round(c["ms"], 4)
+        rr = c.pop("radii")
+        c["radii"] = "%d..%d" % (min(rr), max(rr)) if rr == list(range(min(rr), max(rr) + 1)) else rr
+    return classes, [round(float(v), 4) for v in ms]
+
+
+def secondary(dev):
+    """SURVEY 8d's secondary metric, timed after the headline on the same GPU (N = 1 only)."""
+    import importlib.util
+    import torch
+    import neilpy_amd
+    from neilpy_amd import api
+    out = {}
+    spec = importlib.util.spec_from_file_location("smrf_stages", os.path.join(ROOT, "tools", "smrf_stages.py"))
+    st = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(st)
+    out["smrf_20M"] = st.run(points=20_000_000, extent=8192.0, windows=18, cellsize=1.0)
+    out["smrf_20M"]["workload"] = ("neilpy_amd.smrf on synth_points(2e7, 8192.0, seed=20241), cellsize 1, windows 18, "
+                                   "device-resident points in, device tensors out")
+    torch.cuda.empty_cache()
+    n, nw = 8192, 18
+    Z = torch.from_numpy(neilpy_amd.synth_dem(n, seed=20240, dtype=np.float64)).to(dev)
+    win = np.arange(1, nw + 1)
+    thr = .15 * (win * 1)
+    for _ in range(2):
+        api._progressive_filter_device(Z, win, thr, False, nan_aware=0)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+    evs[0].record()
+    for k in range(5):
+        m, _w = api._progressive_filter_device(Z, win, thr, False, nan_aware=0)
+        evs[k + 1].record()
+    torch.cuda.synchronize()
+    ms = float(np.median([evs[k].elapsed_time(evs[k + 1]) for k in range(5)]))
+    alg = n * n * nw * (5 * 8 + 2)
+    out["progressive_filter_f64_8192_w18"] = {
+        "ms_per_step": ms, "Mcells_per_s": n * n / ms / 1e3, "achieved_gbps": alg / (ms * 1e-3) / 1e9,
+        "frac": alg / (ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_cell_window": 42,
+        "object_cells": int(m.sum().item()),
+        "workload": "progressive_filter core on synth_dem(8192, seed=20240) float64, windows 1..18, median of 5"}
+    return out
+
+
 def main():
     a = parse()
     import torch
     import torch.distributed as dist
     import neilpy_amd
-    from neilpy_amd import api, sharded
+    from neilpy_amd import sharded
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -130,6 +222,14 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+        # a multi-GPU line measured over anything but RCCL is not the metric: refuse, loudly, on every rank
+        if dist.get_backend() != "nccl" and a.backend != "gloo":
+            if rank == 0:
+                print(json.dumps({"error": "process group backend is %r: the N > 1 bench line is defined over nccl (= RCCL); "
+                                           "pass --backend gloo only to rehearse (halos staged through the host)"
+                                           % dist.get_backend()}), file=sys.stderr, flush=True)
+            dist.destroy_process_group()
+            sys.exit(3)
 
     n = a.n
     np_dtype = np.float32 if a.dtype == "f32" else np.float64
@@ -145,7 +245,7 @@ def main():
         crop = np.ascontiguousarray(Z_host[:c, :c])
     del Z_host
 
-    state = {}
+    state = {"profile": True}
 
     def step():
         if world == 1:
@@ -162,22 +262,39 @@ def main():
     for _ in range(a.warmup):
         mask = step()
     barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+    xev = []                                              # N > 1: the exchange events of every timed step
     t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(a.steps):
+    evs[0].record()
+    for k in range(a.steps):
         mask = step()
-    ev1.record()
+        evs[k + 1].record()
+        if world > 1:
+            xev.append((state.get("exchange_events", []), state.get("exchange_bytes", [])))
     barrier()
     dt = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)                       # kernels of this rank's stream only
+    step_ms = np.array([evs[k].elapsed_time(evs[k + 1]) for k in range(a.steps)], dtype=np.float64)
     n_obj = int(mask.sum().item())
+    per_rank = None
     if world > 1:
-        t = torch.tensor([dt, dev_ms, float(n_obj)], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+        exch_ms = np.array([sum(e0.elapsed_time(e1) for e0, e1 in evl) for evl, _ in xev], dtype=np.float64)
+        exch_bytes = float(sum(xev[-1][1])) if xev else 0.0
+        cdev = dev if a.backend == "nccl" else "cpu"
+        t = torch.tensor([dt, float(n_obj)], dtype=torch.float64, device=cdev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        dt, dev_ms, n_obj = float(tmax[0]), float(tmax[1]), int(t[2])
+        dt, n_obj = float(tmax[0]), int(t[1])
+        mine = torch.tensor([float(np.median(step_ms)), float(np.median(exch_ms)), exch_bytes, float(len(xev[-1][0]))],
+                            dtype=torch.float64, device=cdev)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": k, "step_ms": round(float(v[0]), 4), "exchange_ms": round(float(v[1]), 4),
+                     "compute_ms": round(float(v[0] - v[1]), 4), "exchange_bytes_sent": int(v[2]), "exchanges": int(v[3])}
+                    for k, v in enumerate(allr)]
+        sm = torch.tensor(step_ms, dtype=torch.float64, device=cdev)
+        dist.all_reduce(sm, op=dist.ReduceOp.MAX)         # a step is over when its slowest rank is
+        step_ms = sm.cpu().numpy()
 
     # the workload's known answer (tests/test_gpu_fullsize.py pins it): a run, sharded or not, that flags other cells
     # is not a measurement.  Every rank holds the global count here, so every rank leaves with the same exit code.
@@ -206,16 +323,18 @@ def main():
     if rank == 0:
         cells = n * n
         elem = 4 if a.dtype == "f32" else 8
-        ms_per_step = dt / a.steps * 1e3
+        peak = 8000.0
+        ms_median = float(np.median(step_ms))
+        ms_mean = dt / a.steps * 1e3
         # a "pass" is half a window (erosion, or dilation + flag): two ring launches per window, or one fused launch
-        # (disks R <= 8, single device) that does both - the algorithmic bytes per window are SURVEY 8d's 5s + 2 either way
+        # that does both - the algorithmic bytes per window are SURVEY 8d's 5s + 2 either way
         launches = 2 * len(windows)
         alg_bytes_launch = cells / world * (5 * elem + 2) / 2.0  # per rank, per pass
-        avg_launch_s = dev_ms / 1e3 / a.steps / launches
+        avg_launch_s = ms_median / 1e3 / launches
         achieved = alg_bytes_launch / avg_launch_s / 1e9
-        peak = 8000.0
-        # HBM bytes per launch come from rocprofv3 PMC passes, which cannot run inside this process: the committed
-        # summary of the same workload is quoted and labelled as such (tools/profile_round.sh regenerates it)
+        classes, window_ms = (None, None)
+        if world == 1:
+            classes, window_ms = window_classes(Z, windows, thresholds, cells, elem, peak)
         traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         live = None
@@ -241,22 +360,41 @@ def main():
                 traffic = None
         out = {
             "metric": "Mcells/s through SMRF progressive_filter, %dx%d %s DEM" % (n, n, "fp32" if elem == 4 else "fp64"),
-            "value": cells / (dt / a.steps) / 1e6, "unit": "Mcells/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "value": cells / (ms_median * 1e-3) / 1e6, "unit": "Mcells/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": ms_median, "ms_per_step_mean": ms_mean,
+            "step_ms": [round(float(v), 3) for v in step_ms], "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "%s %dx%d %s, windows 1..%d, cellsize 1, slope_threshold 0.15, synth_dem(seed=20240)"
                                    % ("neilpy_amd.progressive_filter (public drop-in call, CUDA tensor in, bool mask out)"
                                       if world == 1 else "sharded.progressive_filter_sharded (row bands)",
                                       n, n, "fp32" if elem == 4 else "fp64", a.windows),
-                       "sharding": "row bands x%d, one halo exchange per group of windows (%d per step, RCCL send/recv)"
-                                   % (world, state.get("exchanges", 0)) if world > 1 else "single device",
-                       "object_cells": n_obj},
+                       "sharding": ({"bands": world, "rows_per_band": n // world, "backend": dist.get_backend(),
+                                     "exchanges_per_step": state.get("exchanges", 0),
+                                     "groups": state.get("groups"),
+                                     "halo_rows_per_exchange": [sum(2 * r for r in g) for g in state.get("groups", [])],
+                                     "message": "RCCL send/recv with rank +- 1, one per group of consecutive windows"}
+                                    if world > 1 else "single device"),
+                       "object_cells": n_obj, "timing": "value and ms_per_step from the median of the per-step device "
+                                                        "times (max over ranks per step); ms_per_step_mean = wall / steps"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-                         "traffic": traffic, "traffic_source": traffic_source, "kernel": "smrf::ring_kernel (two passes per window) and smrf::fused_open_kernel (R <= 8, both passes in one "
-                                   "launch); %d passes per step, achieved = algorithmic bytes per pass / device time per pass" % launches,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "frac_traffic": (traffic / avg_launch_s / 1e9 / peak) if traffic else None,
+                         "kernel": "smrf::ring_kernel (two passes per window) and the fused small-disk launches (both passes of "
+                                   "one or several windows in one launch); %d passes per step, achieved = algorithmic bytes per "
+                                   "pass / median device time per pass" % launches,
                          "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": avg_launch_s * 1e3,
-                         "device_copy_gbps": copy_gbps, "frac_of_device_copy": achieved / copy_gbps},
+                         "device_copy_gbps": copy_gbps, "frac_of_device_copy": achieved / copy_gbps,
+                         "classes": classes, "window_ms": window_ms},
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+        if world == 1 and not a.no_secondary and (n, a.windows, a.dtype) == (16384, 50, "f32"):
+            try:
+                Z = None
+                torch.cuda.empty_cache()
+                out["secondary"] = secondary(dev)
+            except Exception as e:  # noqa: BLE001  (the headline stands on its own)
+                out["secondary"] = {"error": repr(e)[:300]}
         if crop is not None:
             out["cpu_baseline"] = cpu_baseline(crop, windows, cellsize, slope)
         print(json.dumps(out), flush=True)

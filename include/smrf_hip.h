@@ -145,6 +145,24 @@ SMRF_API int smrf_progressive_filter_f64(const double* d_Z, int rows, int cols, 
                                 uint8_t* d_when_dropped, void* d_workspace,
                                 size_t workspace_bytes, int nan_aware, int impl, void* stream);
 
+/* Measurement form of the same call (bench.py's per-class roofline, tools/): an event is recorded on `stream` at
+ * every window boundary and, after the last window has finished (the call synchronises), h_window_ms[i] holds the
+ * device time of window i and h_window_route[i] (may be NULL) how it ran: SMRF_ROUTE_*.  Same result, same routing
+ * as smrf_progressive_filter_*; no reference counterpart (the reference has no timers). */
+#define SMRF_ROUTE_TWO_PASS 0   /* ring erosion, then ring dilation + flag: 5s + 2 B/cell (s = sizeof element) */
+#define SMRF_ROUTE_FUSED 1      /* one fused opening + flag launch: 2s + 2 B/cell */
+#define SMRF_ROUTE_DIRECT 2     /* footprint-gather kernels, two passes (radius > SMRF_RING_MAX_RADIUS or impl = direct) */
+#define SMRF_ROUTE_COPY 3       /* radius 0 */
+#define SMRF_ROUTE_CHAIN 4      /* member of a chain of small windows opened in one launch (route = 4 + position in it) */
+SMRF_API int smrf_progressive_filter_timed_f32(const float* d_Z, int rows, int cols, const int32_t* h_windows,
+                                const double* h_thresholds, int n_windows, uint8_t* d_mask,
+                                uint8_t* d_when_dropped, void* d_workspace, size_t workspace_bytes, int nan_aware,
+                                int impl, void* stream, float* h_window_ms, int32_t* h_window_route);
+SMRF_API int smrf_progressive_filter_timed_f64(const double* d_Z, int rows, int cols, const int32_t* h_windows,
+                                const double* h_thresholds, int n_windows, uint8_t* d_mask,
+                                uint8_t* d_when_dropped, void* d_workspace, size_t workspace_bytes, int nan_aware,
+                                int impl, void* stream, float* h_window_ms, int32_t* h_window_route);
+
 /* number of NaN cells of a contiguous array, written to *h_count (synchronises `stream`) */
 SMRF_API int smrf_count_nan_f32(const float* d_a, int64_t n, int64_t* h_count, void* stream);
 SMRF_API int smrf_count_nan_f64(const double* d_a, int64_t n, int64_t* h_count, void* stream);

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NEILPY_AMD_LIB") or os.path.join(_HERE, "_lib", "libsmrf_hip.so")
 
 IMPL_AUTO, IMPL_RING, IMPL_DIRECT = 0, 1, 2
+ROUTE_TWO_PASS, ROUTE_FUSED, ROUTE_DIRECT, ROUTE_COPY, ROUTE_CHAIN = 0, 1, 2, 3, 4
 RING_MAX_RADIUS = 64
 
 
@@ -39,6 +40,8 @@ SIGNATURES = {
     "smrf_progressive_filter_workspace_bytes": (_sz, [_i, _i, _i]),
     "smrf_progressive_filter_f32": (_i, [_p, _i, _i, _p, _p, _i, _p, _p, _p, _sz, _i, _i, _p]),
     "smrf_progressive_filter_f64": (_i, [_p, _i, _i, _p, _p, _i, _p, _p, _p, _sz, _i, _i, _p]),
+    "smrf_progressive_filter_timed_f32": (_i, [_p, _i, _i, _p, _p, _i, _p, _p, _p, _sz, _i, _i, _p, _p, _p]),
+    "smrf_progressive_filter_timed_f64": (_i, [_p, _i, _i, _p, _p, _i, _p, _p, _p, _sz, _i, _i, _p, _p, _p]),
     "smrf_count_nan_f32": (_i, [_p, _i64, C.POINTER(_i64), _p]),
     "smrf_count_nan_f64": (_i, [_p, _i64, C.POINTER(_i64), _p]),
     "smrf_points_extent_f64": (_i, [_p, _p, _i64, C.POINTER(_d), _p, _sz, _p]),

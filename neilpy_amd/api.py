@@ -139,8 +139,10 @@ def opening(image, footprint=None, *, radius=None, impl=_lib.IMPL_AUTO):
 # ------------------------------------------------------------------------------------------
 # progressive_filter  (neilpy.py:1659-1680)
 # ------------------------------------------------------------------------------------------
-def _progressive_filter_device(Zd, windows, thresholds, want_when, impl=_lib.IMPL_AUTO, nan_aware=-1):
-    """Device-resident core: CUDA raster in, (uint8 mask, uint8 when_dropped | None) CUDA out."""
+def _progressive_filter_device(Zd, windows, thresholds, want_when, impl=_lib.IMPL_AUTO, nan_aware=-1, timing=None):
+    """Device-resident core: CUDA raster in, (uint8 mask, uint8 when_dropped | None) CUDA out.
+    ``timing`` (a dict, measurement runs only): the call goes through ``smrf_progressive_filter_timed_*`` and the dict
+    receives ``window_ms`` (device time per window) and ``route`` (``_lib.ROUTE_*`` per window)."""
     torch = _torch()
     lib = _lib.load()
     rows, cols = Zd.shape
@@ -154,6 +156,15 @@ def _progressive_filter_device(Zd, windows, thresholds, want_when, impl=_lib.IMP
         raise ValueError("windows must be a 1-D array")
     nbytes = lib.smrf_progressive_filter_workspace_bytes(rows, cols, Zd.element_size())
     ws = torch.empty(nbytes, dtype=torch.uint8, device=Zd.device)
+    if timing is not None:
+        ms = np.zeros(win.size, dtype=np.float32)
+        route = np.zeros(win.size, dtype=np.int32)
+        fn = getattr(lib, "smrf_progressive_filter_timed_" + _suffix(Zd))
+        _lib.check(fn(_ptr(Zd), rows, cols, win.ctypes.data_as(C.c_void_p), thr.ctypes.data_as(C.c_void_p),
+                      int(win.size), _ptr(mask), _ptr(when), _ptr(ws), nbytes, int(nan_aware), int(impl), _stream(),
+                      ms.ctypes.data_as(C.c_void_p), route.ctypes.data_as(C.c_void_p)))
+        timing["window_ms"], timing["route"] = ms, route
+        return mask, when
     fn = getattr(lib, "smrf_progressive_filter_" + _suffix(Zd))
     _lib.check(fn(_ptr(Zd), rows, cols, win.ctypes.data_as(C.c_void_p), thr.ctypes.data_as(C.c_void_p),
                   int(win.size), _ptr(mask), _ptr(when), _ptr(ws), nbytes, int(nan_aware), int(impl), _stream()))

@@ -225,7 +225,7 @@ int open_flag_api(const T* last, T* opened, uint8_t* mask, uint8_t* when, double
 template <typename T>
 int progressive_filter_api(const T* Z, int rows, int cols, const int32_t* windows, const double* thr, int nwin,
                            uint8_t* mask, uint8_t* when, void* ws, size_t ws_bytes, int nan_aware, int impl,
-                           void* stream_) {
+                           void* stream_, float* h_window_ms = nullptr, int32_t* h_window_route = nullptr) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!Z || !mask || (nwin > 0 && (!windows || !thr))) return smrf_fail(SMRF_E_ARG, "null pointer");
   if (rows < 1 || cols < 1 || nwin < 0) return smrf_fail(SMRF_E_ARG, "bad size");
@@ -243,6 +243,29 @@ int progressive_filter_api(const T* Z, int rows, int cols, const int32_t* window
     if (int rc = count_nan_api<T>(Z, (int64_t)plane, &c, stream_)) return rc;
     nan_aware = c > 0;
   }
+  // measurement form (smrf_progressive_filter_timed_*): an event on the stream at every window boundary
+  struct Events {                                          // destroyed on every way out
+    std::vector<hipEvent_t> v;
+    ~Events() { for (hipEvent_t e : v) if (e) hipEventDestroy(e); }
+  } evs;
+  std::vector<hipEvent_t>& ev = evs.v;
+  if (h_window_ms) {
+    ev.assign((size_t)nwin + 1, nullptr);
+    for (auto& e : ev) SMRF_HIP_CHECK(hipEventCreate(&e));
+    SMRF_HIP_CHECK(hipEventRecord(ev[0], stream));
+  }
+  auto window_done = [&](int i, int route) -> int {
+    if (h_window_route) h_window_route[i] = route;
+    if (h_window_ms) SMRF_HIP_CHECK(hipEventRecord(ev[(size_t)i + 1], stream));
+    return SMRF_OK;
+  };
+  auto finish = [&]() -> int {
+    if (!h_window_ms) return SMRF_OK;
+    hipError_t e = nwin > 0 ? hipEventSynchronize(ev[(size_t)nwin]) : hipSuccess;
+    for (int i = 0; i < nwin && e == hipSuccess; ++i) e = hipEventElapsedTime(&h_window_ms[i], ev[(size_t)i], ev[(size_t)i + 1]);
+    SMRF_HIP_CHECK(e);
+    return SMRF_OK;
+  };
   const T* last = Z;
   // small disks: opening + flag in ONE launch, the eroded surface never leaves the CU (morph_fused.h; 10 instead of
   // 22 B/cell in fp32).  Not for rasters with NaNs (scipy's NaN rule lives in the two-pass kernels only).
@@ -257,6 +280,7 @@ int progressive_filter_api(const T* Z, int rows, int cols, const int32_t* window
     if (fuse_ok && smrf_fused_radius((int)sizeof(T), r) && (r <= 8 || fuse_mode == 2 || plane >= ((size_t)48 << 20))) {
       if (int rc = open_flag_api<T>(last, opened, mask, when, thr[i], i, rows, cols, cols, 0, rows, 0, rows, r, stream_)) return rc;
       if (nwin > 1) last = opened;
+      if (int rc = window_done(i, SMRF_ROUTE_FUSED)) return rc;
       continue;
     }
     if (int rc = disk_filter_api<T>(last, E, rows, cols, cols, 0, rows, 0, rows, r, 0, nan_aware, impl, stream_)) return rc;
@@ -264,8 +288,10 @@ int progressive_filter_api(const T* Z, int rows, int cols, const int32_t* window
                                     nan_aware, impl, stream_))
       return rc;
     if (nwin > 1) last = opened;                        // neilpy.py:1675-1676
+    const int eff = impl == SMRF_IMPL_AUTO ? (r <= SMRF_RING_MAX_RADIUS ? SMRF_IMPL_RING : SMRF_IMPL_DIRECT) : impl;
+    if (int rc = window_done(i, r == 0 ? SMRF_ROUTE_COPY : eff == SMRF_IMPL_RING ? SMRF_ROUTE_TWO_PASS : SMRF_ROUTE_DIRECT)) return rc;
   }
-  return SMRF_OK;
+  return finish();
 }
 
 }  // namespace
@@ -329,6 +355,22 @@ int smrf_progressive_filter_f64(const double* d_Z, int rows, int cols, const int
                                 void* d_workspace, size_t workspace_bytes, int nan_aware, int impl, void* stream) {
   return progressive_filter_api<double>(d_Z, rows, cols, h_windows, h_thresholds, n_windows, d_mask, d_when_dropped,
                                         d_workspace, workspace_bytes, nan_aware, impl, stream);
+}
+int smrf_progressive_filter_timed_f32(const float* d_Z, int rows, int cols, const int32_t* h_windows,
+                                      const double* h_thresholds, int n_windows, uint8_t* d_mask, uint8_t* d_when_dropped,
+                                      void* d_workspace, size_t workspace_bytes, int nan_aware, int impl, void* stream,
+                                      float* h_window_ms, int32_t* h_window_route) {
+  if (!h_window_ms) return smrf_fail(SMRF_E_ARG, "null h_window_ms");
+  return progressive_filter_api<float>(d_Z, rows, cols, h_windows, h_thresholds, n_windows, d_mask, d_when_dropped,
+                                       d_workspace, workspace_bytes, nan_aware, impl, stream, h_window_ms, h_window_route);
+}
+int smrf_progressive_filter_timed_f64(const double* d_Z, int rows, int cols, const int32_t* h_windows,
+                                      const double* h_thresholds, int n_windows, uint8_t* d_mask, uint8_t* d_when_dropped,
+                                      void* d_workspace, size_t workspace_bytes, int nan_aware, int impl, void* stream,
+                                      float* h_window_ms, int32_t* h_window_route) {
+  if (!h_window_ms) return smrf_fail(SMRF_E_ARG, "null h_window_ms");
+  return progressive_filter_api<double>(d_Z, rows, cols, h_windows, h_thresholds, n_windows, d_mask, d_when_dropped,
+                                        d_workspace, workspace_bytes, nan_aware, impl, stream, h_window_ms, h_window_route);
 }
 int smrf_count_nan_f32(const float* d_a, int64_t n, int64_t* h_count, void* stream) {
   return count_nan_api<float>(d_a, n, h_count, stream);

@@ -114,10 +114,25 @@ __global__ __launch_bounds__(256) void atu_kernel(const Band b) {
   __shared__ double red[4];
   __shared__ double red2[4];
   const Sc* sc = b.sc;
-  if (stopped(sc) || !sc->beta_pos) return;
-  const double ib = sc->inv_beta, ia = sc->inv_alfa, beta = sc->beta;
+  if (stopped(sc)) return;
   const int rows = b.rows, cols = b.cols;
   const long long ld = b.ld;
+  if (!sc->beta_pos) {
+    // beta == 0 (u = 0: the exact solution is reached): v and alfa stay as they are (lsqr.py:434-441), but the
+    // row-band form's tests still take |dk|^2 from this phase's |w|^2, so that half is written all the same
+    if constexpr (WSUM) {
+      double sw0 = 0.0;
+      SMRF_FOR_CELLS_P(rows, cols, ld) {
+        if (!b.hole[i]) continue;
+        const double ws = b.w[i];
+        sw0 += ws * ws;
+      }
+      const double tw0 = block_sum(sw0, red2);
+      if (threadIdx.x == 0) b.part[MAXB + blockIdx.y * gridDim.x + blockIdx.x] = tw0;
+    }
+    return;
+  }
+  const double ib = sc->inv_beta, ia = sc->inv_alfa, beta = sc->beta;
   double s = 0.0, sw = 0.0;
   SMRF_FOR_CELLS_P(rows, cols, ld) {
     if (!b.hole[i]) continue;

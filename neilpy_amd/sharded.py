@@ -155,7 +155,8 @@ def progressive_filter_sharded(Z_band, img_rows, windows, thresholds, *, rank=No
     ``thresholds`` = ``slope_threshold * (windows * cellsize)`` in float64, as on one device.
     Every band must have at least ``2 * max(windows)`` rows (a halo never spans two ranks).
     ``state`` (a dict) keeps the extended buffers between calls so a benchmark loop does not
-    re-allocate (and reports ``state["exchanges"]``).  ``halo_budget``: rows of halo a group of
+    re-allocate (and reports ``state["exchanges"]``; with ``state["profile"] = True`` also ``exchange_events``, a pair
+    of CUDA events around every exchange, ``exchange_bytes``, the bytes this rank sent in each, and ``groups``).  ``halo_budget``: rows of halo a group of
     consecutive windows may share in one exchange (see :func:`window_groups`; 0 = one exchange
     per window).  ``overlap=True`` splits every group's last dilation edge-first and posts the next group's exchange
     on a side stream beside the interior (module docstring).  Off by default: on a 2048-row band the two edge
@@ -223,12 +224,24 @@ def progressive_filter_sharded(Z_band, img_rows, windows, thresholds, *, rank=No
     if side is None and Z_band.is_cuda and world_size > 1:
         side = st["side"] = torch.cuda.Stream(device=dev)
     M_of = [sum(2 * windows[i] for i in g) if world_size > 1 else 0 for g in groups]
+    st["groups"] = [[windows[i] for i in g] for g in groups]
+
+    profile = bool(st.get("profile")) and Z_band.is_cuda      # bench.py: events either side of every exchange
+    if profile:
+        st["exchange_events"], st["exchange_bytes"] = [], []
 
     def exchange(last, M):
         lo, hi = max(0, b0 - M), min(img_rows, b1 + M)
+        if profile:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         _exchange(dist, group, rank, world_size,
                   last[off:off + M], last[lo - e0:off] if rank > 0 else None,
                   last[off + nloc - M:off + nloc], last[off + nloc:hi - e0] if rank < world_size - 1 else None)
+        if profile:
+            ev1.record()
+            st["exchange_events"].append((ev0, ev1))
+            st["exchange_bytes"].append(M * cols * Z_band.element_size() * ((rank > 0) + (rank < world_size - 1)))
         st["exchanges"] += 1
 
     posted = None                                            # event of an exchange posted ahead for the next group
@@ -549,7 +562,8 @@ def create_dem_sharded(xd, yd, zd, cellsize=1, bin_type='max', *, rank=None, wor
     """create_dem (neilpy/neilpy.py:1110-1166) with the POINTS sharded: every rank passes its own 1/N of the cloud
     and gets its row band of the raster - nothing is replicated (the all-to-all form).
 
-    1. extents: local min/max (device reduction), one 4-double all-reduce(min) -> the same edges, shape and
+    1. extents: local min/max (device reduction), a count of ranks with an undefined extent (all-reduce sum) and one
+       4-double all-reduce(min) -> the same edges, shape and
        transform on every rank (:1117-1124, :1141);
     2. every point is routed to the rank whose band holds ``floor(row)`` of ``~t * (x, y)`` - bucketed on the device
        (count, prefix sum, pack), the counts and then the three coordinate runs exchanged with ``all_to_all_single``
@@ -573,12 +587,20 @@ def create_dem_sharded(xd, yd, zd, cellsize=1, bin_type='max', *, rank=None, wor
     multi = world_size > 1
     gloo = multi and dist.get_backend(group) == "gloo"
     xmin, xmax, ymin, ymax = ops.extent(xd, yd)
+    # A rank whose extent is undefined (a NaN / inf coordinate, or no points) must stop EVERY rank.  MIN does not carry
+    # a NaN reliably (RCCL's float min is fmin-like and drops it, gloo's std::min keeps it or not by operand order), so
+    # the ranks agree on an explicit count of bad extents first and only reduce finite values.
+    bad = int(not np.isfinite([xmin, xmax, ymin, ymax]).all())
+    if multi:
+        nb = torch.tensor([bad], dtype=torch.int32, device="cpu" if gloo else xd.device)
+        dist.all_reduce(nb, op=dist.ReduceOp.SUM, group=group)
+        bad = int(nb.item())
+    if bad:
+        raise ValueError("zero-size or non-finite point set: the raster's extent is undefined")
     if multi:
         e = torch.tensor([xmin, ymin, -xmax, -ymax], dtype=torch.float64, device="cpu" if gloo else xd.device)
-        dist.all_reduce(e, op=dist.ReduceOp.MIN, group=group)          # a NaN coordinate anywhere makes them NaN, as np.min
+        dist.all_reduce(e, op=dist.ReduceOp.MIN, group=group)
         xmin, ymin, xmax, ymax = float(e[0]), float(e[1]), -float(e[2]), -float(e[3])
-    if not np.isfinite([xmin, xmax, ymin, ymax]).all():
-        raise ValueError("zero-size or non-finite point set: the raster's extent is undefined")
     xedges, yedges = api._edges_from_extent(np.float64(xmin), np.float64(xmax), np.float64(ymin), np.float64(ymax), cellsize)
     nx, ny = len(xedges) - 1, len(yedges) - 1
     t = from_origin(xedges[0], yedges[0], cellsize, cellsize)

@@ -352,6 +352,41 @@ def golden_progressive_filter(ref, rec, out):
     np.savez_compressed(os.path.join(out, "progressive_filter.npz"), **d)
 
 
+def golden_pf_w50(ref, out, which):
+    """The benchmark's window list (1..50, fp32 synth_dem) through the reference's progressive_filter
+    (neilpy/neilpy.py:1659-1680): ``mid`` = 768 x 1024 (4 strips of 256 columns, several segments on the
+    device; about 5 min), ``big`` = 2048 x 2048 (the raster of SURVEY 8d's CPU baseline; about 30 min).
+    The last opened surface is taken from the reference's own run by recording what its ``opening`` returns."""
+    rows, n, seed = dict(mid=(768, 1024, 20240), big=(2048, 2048, 20240))[which]
+    Z = synth_dem(n, seed=seed, dtype=np.float32, rows=rows)
+    windows = np.arange(1, 51)
+    seen = {}
+    real_opening = ref.opening
+
+    def recording_opening(image, footprint=None):
+        seen["last"] = real_opening(image, footprint)
+        seen["count"] = seen.get("count", 0) + 1
+        return seen["last"]
+
+    ref.opening = recording_opening
+    try:
+        m, wd = ref.progressive_filter(Z, windows, 1, .15, return_when_dropped=True)
+    finally:
+        ref.opening = real_opening
+    assert seen["count"] == 50 and m.dtype == bool and wd.dtype == np.uint8
+    d = dict(shape=np.array(Z.shape), seed=np.array(seed), Z_sha1=np.array(sha(Z)), windows=windows,
+             params=np.array([1, .15], dtype=np.float64), mask_bits=pack(m), object_cells=np.array(int(m.sum())),
+             when_dropped_sha1=np.array(sha(wd)), opened_last_sha1=np.array(sha(seen["last"])))
+    if which == "mid":
+        d["when_dropped"] = wd
+        d["opened_last"] = seen["last"]
+    else:
+        d["when_dropped_hist"] = np.bincount(wd[m].ravel(), minlength=50)
+        d["opened_last_rowsum"] = seen["last"].astype(np.float64).sum(axis=1)
+    np.savez_compressed(os.path.join(out, "progressive_filter_w50_%s.npz" % which), **d)
+    print("pf_w50", which, Z.shape, int(m.sum()), flush=True)
+
+
 def golden_inpaint(ref, rec, out):
     d = {}
     cases = []
@@ -637,6 +672,9 @@ def main():
     ref = import_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "las":
         golden_las(ref, out)
+        return
+    if len(sys.argv) > 2 and sys.argv[1] == "pf_w50":        # not part of the default run: minutes of CPU
+        golden_pf_w50(ref, out, sys.argv[2])
         return
     if len(sys.argv) > 1 and sys.argv[1] == "pssm":
         golden_pssm(ref, out)

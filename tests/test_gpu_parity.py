@@ -341,7 +341,7 @@ def test_sharded_two_ranks_on_one_gpu(nz, tmp_path):
     import subprocess
     import sys
     from conftest import ROOT
-    common = ["--size", "1024", "--windows", "12", "--steps", "1", "--warmup", "1", "--no-cpu"]
+    common = ["--size", "1024", "--windows", "12", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-pmc", "--no-secondary"]
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common,
                          capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
@@ -353,6 +353,42 @@ def test_sharded_two_ranks_on_one_gpu(nz, tmp_path):
     j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
     assert j2["n_gpus"] == 2 and j1["config"]["object_cells"] == j2["config"]["object_cells"]
+    # the N = 1 line: median step, per-class split priced at the bytes each class moves (nothing above the peak)
+    assert len(j1["step_ms"]) == 3 and abs(j1["ms_per_step"] - sorted(j1["step_ms"])[1]) < 1e-6
+    cl = j1["roofline"]["classes"]
+    assert sum(c["windows"] for c in cl.values()) == 12 and all(c["gbps"] < 8000.0 for c in cl.values())
+    assert len(j1["roofline"]["window_ms"]) == 12
+    # the N = 2 line: per-rank compute / exchange split and the exchange schedule
+    sh = j2["config"]["sharding"]
+    assert sh["bands"] == 2 and sh["backend"] == "gloo" and sh["exchanges_per_step"] == len(sh["groups"])
+    assert sorted(r for g in sh["groups"] for r in g) == list(range(1, 13))
+    assert len(j2["per_rank"]) == 2
+    for pr in j2["per_rank"]:
+        assert pr["exchanges"] == sh["exchanges_per_step"] and pr["exchange_ms"] > 0 and pr["compute_ms"] > 0
+        assert pr["exchange_bytes_sent"] == sum(sh["halo_rows_per_exchange"]) * 1024 * 4
+
+
+def test_bench_two_ranks_nccl_needs_two_devices(nz):
+    """the first real RCCL run of bench.py's N = 2 path: only where two GPUs are visible (never on the one-GPU box)"""
+    import json
+    import subprocess
+    import sys
+    import torch
+    from conftest import ROOT
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: RCCL halo exchange needs two devices")
+    common = ["--size", "4096", "--windows", "18", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-pmc", "--no-secondary"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common,
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2"] + common, capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert j2["config"]["sharding"]["backend"] == "nccl"
+    assert j1["config"]["object_cells"] == j2["config"]["object_cells"]
 
 
 def test_spline_matches_scipy(nz, gpu_device):

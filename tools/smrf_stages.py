@@ -2,6 +2,12 @@
 """Per-stage timing of the full device SMRF path on synthetic lidar points (secondary metric of SURVEY 8d).
 
     python tools/smrf_stages.py --points 20000000 --extent 8192 --windows 18
+
+``run()`` is also what bench.py's ``secondary`` block calls.  Stages are timed one by one (synchronise, wall clock)
+on device-resident points, then the public ``neilpy_amd.smrf`` call is timed as a whole on the same tensors.
+LSQR figures: ``ms_per_iteration`` and ``gbps`` = 106 B x raster cells / that time - the bytes one iteration of the
+matrix-free solver moves over its planes (u two planes, v, w, x float64 read + written where a hole is, plus the hole
+bytes) - so the figure is the kernels' own traffic model, an upper bound on rasters with few holes.
 """
 import argparse
 import json
@@ -11,66 +17,82 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--points", type=int, default=20_000_000)
-ap.add_argument("--extent", type=float, default=8192.0)
-ap.add_argument("--windows", type=int, default=18)
-ap.add_argument("--cellsize", type=float, default=1.0)
-a = ap.parse_args()
-
-import torch  # noqa: E402
-import neilpy_amd  # noqa: E402
-from neilpy_amd import api, _lib  # noqa: E402
-
-x, y, z = neilpy_amd.synth_points(a.points, a.extent, seed=20241)
-t0 = time.perf_counter()
-xd, yd, zd = api._points_to_device(x, y, z)
-torch.cuda.synchronize()
-stages = {"upload_ms": (time.perf_counter() - t0) * 1e3}
-lib = _lib.load()
+LSQR_BYTES_PER_CELL_ITER = 106.0
 
 
-def timed(name, fn):
+def run(points=20_000_000, extent=8192.0, windows=18, cellsize=1.0, seed=20241):
+    import torch
+    import neilpy_amd
+    from neilpy_amd import api, _lib
+
+    x, y, z = neilpy_amd.synth_points(points, extent, seed=seed)
+    t0 = time.perf_counter()
+    xd, yd, zd = api._points_to_device(x, y, z)
     torch.cuda.synchronize()
-    t = time.perf_counter()
-    out = fn()
+    stages = {"upload_ms": (time.perf_counter() - t0) * 1e3}
+    del x, y, z
+    lib = _lib.load()
+
+    def timed(name, fn):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        stages[name] = (time.perf_counter() - t) * 1e3
+        return out
+
+    cs = int(cellsize) if cellsize == int(cellsize) else cellsize
+    win = np.arange(windows) + 1
+    Zmin, empty, t = timed("create_dem_ms", lambda: api._create_dem_device(xd, yd, zd, cs, "min", None))
+    rows, cols = Zmin.shape
+    stages["grid"] = [rows, cols]
+    stages["empty_fraction"] = float(empty.float().mean().item())
+
+    def lsqr(name):
+        timed(name + "_ms", lambda: api._springs_device(Zmin, name))
+        st = dict(api.last_stats[name])
+        st["ms_per_iteration"] = stages[name + "_ms"] / max(1, st["itn"])
+        st["gbps"] = LSQR_BYTES_PER_CELL_ITER * rows * cols / (st["ms_per_iteration"] * 1e-3) / 1e9
+        stages[name] = st
+
+    lsqr("inpaint1")
+
+    def low_filter():
+        neg = torch.empty_like(Zmin)
+        _lib.check(lib.smrf_negate_f64(api._ptr(Zmin), api._ptr(neg), Zmin.numel(), api._stream()))
+        return api._progressive_filter_device(neg, np.array([1]), 5 * (np.array([1]) * cs), False, nan_aware=0)[0]
+
+    low = timed("low_outlier_filter_ms", low_filter)
+    obj = timed("progressive_filter_f64_ms",
+                lambda: api._progressive_filter_device(Zmin, win, .15 * (win * cs), False, nan_aware=0)[0])
+    object_cells = torch.empty_like(obj)
+    timed("mask_apply_ms", lambda: _lib.check(lib.smrf_mask_apply_f64(api._ptr(Zmin), api._ptr(empty), api._ptr(low),
+                                                                      api._ptr(obj), api._ptr(object_cells), Zmin.numel(),
+                                                                      api._stream())))
+    stages["object_fraction"] = float(object_cells.float().mean().item())
+    lsqr("inpaint2")
+    del Zmin, empty, low, obj, object_cells
     torch.cuda.synchronize()
-    stages[name] = (time.perf_counter() - t) * 1e3
-    return out
+    t_all = time.perf_counter()
+    out = neilpy_amd.smrf(xd, yd, zd, cellsize=cs, windows=windows)
+    torch.cuda.synchronize()
+    stages["smrf_total_ms"] = (time.perf_counter() - t_all) * 1e3
+    stages["points"] = points
+    stages["Mpoints_per_s"] = points / stages["smrf_total_ms"] / 1e3
+    stages["object_points"] = int(out[3].sum().item())          # CUDA tensors in -> CUDA tensors out
+    stages["lsqr_bytes_model"] = "%.0f B x raster cells per iteration (DESIGN 4.3)" % LSQR_BYTES_PER_CELL_ITER
+    return stages
 
 
-cs = int(a.cellsize) if a.cellsize == int(a.cellsize) else a.cellsize
-windows = np.arange(a.windows) + 1
-Zmin, empty, t = timed("create_dem_ms", lambda: api._create_dem_device(xd, yd, zd, cs, "min", None))
-rows, cols = Zmin.shape
-stages["grid"] = [rows, cols]
-stages["empty_fraction"] = float(empty.float().mean().item())
-timed("inpaint1_ms", lambda: api._springs_device(Zmin, "inpaint1"))
-stages["inpaint1"] = dict(api.last_stats["inpaint1"])
-
-
-def low_filter():
-    neg = torch.empty_like(Zmin)
-    _lib.check(lib.smrf_negate_f64(api._ptr(Zmin), api._ptr(neg), Zmin.numel(), api._stream()))
-    return api._progressive_filter_device(neg, np.array([1]), 5 * (np.array([1]) * cs), False, nan_aware=0)[0]
-
-
-low = timed("low_outlier_filter_ms", low_filter)
-obj = timed("progressive_filter_f64_ms",
-            lambda: api._progressive_filter_device(Zmin, windows, .15 * (windows * cs), False, nan_aware=0)[0])
-object_cells = torch.empty_like(obj)
-timed("mask_apply_ms", lambda: _lib.check(lib.smrf_mask_apply_f64(api._ptr(Zmin), api._ptr(empty), api._ptr(low), api._ptr(obj),
-                                                                  api._ptr(object_cells), Zmin.numel(), api._stream())))
-stages["object_fraction"] = float(object_cells.float().mean().item())
-timed("inpaint2_ms", lambda: api._springs_device(Zmin, "inpaint2"))
-stages["inpaint2"] = dict(api.last_stats["inpaint2"])
-t_all = time.perf_counter()
-out = neilpy_amd.smrf(xd, yd, zd, cellsize=cs, windows=a.windows)
-torch.cuda.synchronize()
-stages["smrf_total_ms"] = (time.perf_counter() - t_all) * 1e3
-stages["points"] = a.points
-stages["Mpoints_per_s"] = a.points / stages["smrf_total_ms"] / 1e3
-stages["object_points"] = int(out[3].sum().item())          # CUDA tensors in -> CUDA tensors out
-print(json.dumps(stages))
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--points", type=int, default=20_000_000)
+    ap.add_argument("--extent", type=float, default=8192.0)
+    ap.add_argument("--windows", type=int, default=18)
+    ap.add_argument("--cellsize", type=float, default=1.0)
+    a = ap.parse_args()
+    print(json.dumps(run(a.points, a.extent, a.windows, a.cellsize)))
