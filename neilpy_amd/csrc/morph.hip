@@ -15,6 +15,20 @@ namespace {
 // O(card(disk)) loads per cell - the fallback for radius > SMRF_RING_MAX_RADIUS and the
 // independent on-device cross-check of the ring kernels in the parity tests.
 // ------------------------------------------------------------------------------------------
+// the flag step of one output cell (neilpy.py:1671-1674): sparse, or dense when the planes were not cleared (DiskArgs::dense)
+template <typename T>
+__device__ __forceinline__ void flag_cell(const DiskArgs<T>& a, long long off, T lastval, T val) {
+  const T diff = lastval - val;                            // raster dtype
+  const bool hit = (double)diff > a.thr;                   // float64 comparison (NumPy 2)
+  if (a.dense) {
+    a.mask[off] = hit ? 1 : 0;
+    if (a.when != nullptr) a.when[off] = hit ? (uint8_t)a.widx : (uint8_t)0;
+  } else if (hit) {
+    a.mask[off] = 1;
+    if (a.when != nullptr) a.when[off] = (uint8_t)a.widx;
+  }
+}
+
 template <typename T, bool DIL>
 __global__ __launch_bounds__(256) void direct_kernel(const DiskArgs<T> a) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -40,13 +54,7 @@ __global__ __launch_bounds__(256) void direct_kernel(const DiskArgs<T> a) {
   if (a.nan_aware && first_nan) best = DIL ? (T)NAN : (T)NAN;
   const long long off = (long long)(y - a.out_row0) * a.ld + x;
   a.out[off] = best;
-  if (a.mask != nullptr) {
-    const T diff = a.last[off] - best;
-    if ((double)diff > a.thr) {
-      a.mask[off] = 1;
-      if (a.when != nullptr) a.when[off] = (uint8_t)a.widx;
-    }
-  }
+  if (a.mask != nullptr) flag_cell(a, off, a.last[off], best);
 }
 
 template <typename T>
@@ -57,13 +65,7 @@ __global__ __launch_bounds__(256) void copy_flag_kernel(const DiskArgs<T> a) {  
     const T v = a.in[(long long)(a.out_row0 + yy - a.in_row0) * a.ld + x];
     const long long off = (long long)yy * a.ld + x;
     a.out[off] = v;
-    if (a.mask != nullptr) {
-      const T diff = a.last[off] - v;
-      if ((double)diff > a.thr) {
-        a.mask[off] = 1;
-        if (a.when != nullptr) a.when[off] = (uint8_t)a.widx;
-      }
-    }
+    if (a.mask != nullptr) flag_cell(a, off, a.last[off], v);
   }
 }
 
@@ -161,26 +163,35 @@ int disk_filter(DiskArgs<T> a, bool dilate, int impl, hipStream_t stream) {
   return SMRF_OK;
 }
 
+// output cells as non-temporal stores (DiskArgs::nt): when a plane is far larger than what the caches can hand to the
+// next launch (16384^2 fp32, 1 GiB per plane: -1.7 % on the whole progressive_filter; 4096^2, 64 MB: +2 %).  SMRF_NT=0|1 forces it.
+template <typename T>
+int nt_rule(int img_rows, int cols) {
+  const int env = smrf_env_int("SMRF_NT", -1);
+  if (env >= 0) return env != 0;
+  return (size_t)img_rows * (size_t)cols * sizeof(T) >= ((size_t)192 << 20);
+}
+
 template <typename T>
 int disk_filter_api(const T* in, T* out, int img_rows, int cols, int64_t ld, int in_row0, int in_rows,
                     int out_row0, int out_rows, int radius, int is_dilate, int nan_aware, int impl, void* stream) {
   DiskArgs<T> a{};
   a.in = in; a.out = out; a.img_rows = img_rows; a.cols = cols; a.ld = ld;
   a.in_row0 = in_row0; a.in_rows = in_rows; a.out_row0 = out_row0; a.out_rows = out_rows;
-  a.radius = radius; a.nan_aware = nan_aware;
+  a.radius = radius; a.nan_aware = nan_aware; a.nt = nt_rule<T>(img_rows, cols);
   return disk_filter(a, is_dilate != 0, impl, (hipStream_t)stream);
 }
 
 template <typename T>
 int dilate_flag_api(const T* eroded, const T* last, T* opened, uint8_t* mask, uint8_t* when, double thr,
                     int widx, int img_rows, int cols, int64_t ld, int in_row0, int in_rows, int out_row0,
-                    int out_rows, int radius, int nan_aware, int impl, void* stream) {
+                    int out_rows, int radius, int nan_aware, int impl, void* stream, int dense = 0) {
   if (!last || !mask) return smrf_fail(SMRF_E_ARG, "null last/mask pointer");
   DiskArgs<T> a{};
   a.in = eroded; a.out = opened; a.last = last; a.mask = mask; a.when = when; a.thr = thr; a.widx = widx;
   a.img_rows = img_rows; a.cols = cols; a.ld = ld;
   a.in_row0 = in_row0; a.in_rows = in_rows; a.out_row0 = out_row0; a.out_rows = out_rows;
-  a.radius = radius; a.nan_aware = nan_aware;
+  a.radius = radius; a.nan_aware = nan_aware; a.nt = nt_rule<T>(img_rows, cols); a.dense = dense;
   return disk_filter(a, true, impl, (hipStream_t)stream);
 }
 
@@ -206,7 +217,7 @@ int count_nan_api(const T* p, int64_t n, int64_t* h_count, void* stream_) {
 
 template <typename T>
 int open_flag_api(const T* last, T* opened, uint8_t* mask, uint8_t* when, double thr, int widx, int img_rows, int cols,
-                  int64_t ld, int in_row0, int in_rows, int out_row0, int out_rows, int radius, void* stream) {
+                  int64_t ld, int in_row0, int in_rows, int out_row0, int out_rows, int radius, void* stream, int dense = 0) {
   if (!smrf_fused_radius((int)sizeof(T), radius))
     return smrf_fail(SMRF_E_UNSUPPORTED, "no fused opening kernel for radius %d at this dtype", radius);
   DiskArgs<T> a{};
@@ -218,6 +229,8 @@ int open_flag_api(const T* last, T* opened, uint8_t* mask, uint8_t* when, double
   a.radius = radius;
   a.last = last + (long long)(out_row0 - in_row0) * ld; // the flag step compares against the same surface
   a.nan_aware = 0;
+  a.nt = nt_rule<T>(img_rows, cols);
+  a.dense = mask ? dense : 0;
   a.seg = smrf_env_int("SMRF_RING_SEG", 0);
   return RingFn<T>::call(a, SMRF_RING_FUSED_OPEN, (hipStream_t)stream);
 }
@@ -236,8 +249,12 @@ int progressive_filter_api(const T* Z, int rows, int cols, const int32_t* window
   const size_t plane = (size_t)rows * cols;
   T* E = reinterpret_cast<T*>(ws);
   T* O[2] = {E + plane, E + 2 * plane};
-  SMRF_HIP_CHECK(hipMemsetAsync(mask, 0, plane, stream));
-  if (when) SMRF_HIP_CHECK(hipMemsetAsync(when, 0, plane, stream));
+  // The first window's flag step writes every mask / when byte (DiskArgs::dense), so the planes are not cleared first:
+  // one coalesced byte per cell instead of a memset pass plus scattered single-byte stores (window 0 flags the most cells)
+  if (nwin == 0) {
+    SMRF_HIP_CHECK(hipMemsetAsync(mask, 0, plane, stream));
+    if (when) SMRF_HIP_CHECK(hipMemsetAsync(when, 0, plane, stream));
+  }
   if (nan_aware < 0) {
     int64_t c = 0;
     if (int rc = count_nan_api<T>(Z, (int64_t)plane, &c, stream_)) return rc;
@@ -278,14 +295,14 @@ int progressive_filter_api(const T* Z, int rows, int cols, const int32_t* window
     // above R = 8 the fused kernel's 4R warm-up rows per segment only pay on rasters large enough for long segments
     // (4096^2, windows 1..18: 1.64 ms with R <= 8 fused, 1.70 ms with 10..14 as well; 8192^2: 5.9 -> 5.2 ms with them)
     if (fuse_ok && smrf_fused_radius((int)sizeof(T), r) && (r <= 8 || fuse_mode == 2 || plane >= ((size_t)48 << 20))) {
-      if (int rc = open_flag_api<T>(last, opened, mask, when, thr[i], i, rows, cols, cols, 0, rows, 0, rows, r, stream_)) return rc;
+      if (int rc = open_flag_api<T>(last, opened, mask, when, thr[i], i, rows, cols, cols, 0, rows, 0, rows, r, stream_, i == 0)) return rc;
       if (nwin > 1) last = opened;
       if (int rc = window_done(i, SMRF_ROUTE_FUSED)) return rc;
       continue;
     }
     if (int rc = disk_filter_api<T>(last, E, rows, cols, cols, 0, rows, 0, rows, r, 0, nan_aware, impl, stream_)) return rc;
     if (int rc = dilate_flag_api<T>(E, last, opened, mask, when, thr[i], i, rows, cols, cols, 0, rows, 0, rows, r,
-                                    nan_aware, impl, stream_))
+                                    nan_aware, impl, stream_, i == 0))
       return rc;
     if (nwin > 1) last = opened;                        // neilpy.py:1675-1676
     const int eff = impl == SMRF_IMPL_AUTO ? (r <= SMRF_RING_MAX_RADIUS ? SMRF_IMPL_RING : SMRF_IMPL_DIRECT) : impl;

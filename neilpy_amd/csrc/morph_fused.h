@@ -36,6 +36,20 @@ constexpr int fused_np(int r) {
   return sizeof(T) == 4 ? ((r == 2 || r == 3 || r == 8 || r == 10) ? 1 : 2) : 1;
 }
 
+// `last` for the flag step from a register queue instead of a second read from memory.  The flag step of opened row y
+// needs last[y], which the workgroup staged 2R rows earlier as erosion input; read again from global memory it comes
+// from HBM, not from the L2 (PMC, profiles/r03_fused_flag_traffic.md: +1.0 GiB of reads per window at every radius
+// from 2 up, 0.10-0.18 ms of a 0.6-0.9 ms launch - eight workgroups per CU stream more rows through an XCD's 4 MB L2
+// in 2R + 2 batches than it holds).  The queue keeps the lane's own column of the last ceil(2R / ROWS) batches in
+// registers (2 * NP per batch, moved down once per batch: v_mov at 2.1 cycles).  Per radius, measured.
+#ifndef SMRF_FUSED_LASTQ
+#define SMRF_FUSED_LASTQ(T, R) fused_lastq<T>(R)
+#endif
+template <typename T>
+constexpr bool fused_lastq(int r) {   // gpurun_out/r03k/lq.log: fp32 R = 2..7 -9...-17 %, R >= 8 lose a workgroup per CU to the queue's registers
+  return sizeof(T) == 4 ? (r >= 2 && r <= 7) : (r == 1 || r == 2 || r == 4 || r == 5);
+}
+
 // workgroups per CU the kernel is built for: what the two tables' LDS allows, at most 4 (128 registers per lane)
 template <typename T, int R, int TW, int NP>
 constexpr int fused_min_blocks() {
@@ -120,13 +134,29 @@ void fused_open_kernel(const DiskArgs<T> a) {
     }
     rf.advance(ROWS);
   };
-  auto emit = [&](long long off, T val, T lastval) {
-    a.out[off] = val;
-    if (flag) {
-      const T diff = lastval - val;                        // raster dtype
-      if ((double)diff > a.thr) {                          // float64 comparison (NumPy 2)
-        a.mask[off] = 1;
-        if (a.when != nullptr) a.when[off] = (uint8_t)a.widx;
+  auto emit = [&](long long off, T val, T lastval) {       // one opened cell, general form
+    smrf_store_out(&a.out[off], val, a.nt);
+    if (flag) smrf_flag_cell(a, off, lastval, val);
+  };
+  // a batch whose ROWS opened rows are all inside the segment, as straight-line code per (store kind, flag step: none,
+  // sparse, dense): the uniform tests once per batch instead of once per cell
+  auto emit_rows = [&]<bool NT, int MODE>(std::bool_constant<NT>, std::integral_constant<int, MODE>, long long off0)
+                       __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      const long long off = off0 + (long long)i * a.ld;
+      if constexpr (NT) __builtin_nontemporal_store(outvD[i], &a.out[off]);
+      else a.out[off] = outvD[i];
+      if constexpr (MODE != 0) {
+        const T diff = lastv[i] - outvD[i];                  // raster dtype
+        const bool hit = (double)diff > a.thr;               // float64 comparison (NumPy 2)
+        if constexpr (MODE == 2) {                           // first window of a call: every byte, the planes were not cleared
+          a.mask[off] = hit ? 1 : 0;
+          if (a.when != nullptr) a.when[off] = hit ? (uint8_t)a.widx : (uint8_t)0;
+        } else if (hit) {
+          a.mask[off] = 1;
+          if (a.when != nullptr) a.when[off] = (uint8_t)a.widx;
+        }
       }
     }
   };
@@ -135,8 +165,16 @@ void fused_open_kernel(const DiskArgs<T> a) {
     if (yob < ys || !writes) return;
     const long long off0 = (long long)(yob - a.out_row0) * a.ld + x;
     if (yob + ROWS <= ye) {
-#pragma unroll
-      for (int i = 0; i < ROWS; ++i) emit(off0 + (long long)i * a.ld, outvD[i], lastv[i]);
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      if (!flag) {
+        if (a.nt) emit_rows(std::true_type{}, I0{}, off0); else emit_rows(std::false_type{}, I0{}, off0);
+      } else if (!a.dense) {
+        if (a.nt) emit_rows(std::true_type{}, I1{}, off0); else emit_rows(std::false_type{}, I1{}, off0);
+      } else {
+        if (a.nt) emit_rows(std::true_type{}, I2{}, off0); else emit_rows(std::false_type{}, I2{}, off0);
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < ROWS; ++i)
@@ -153,6 +191,14 @@ void fused_open_kernel(const DiskArgs<T> a) {
       lastv[i] = a.last[(long long)yo * a.ld + xc];
     }
   };
+
+  constexpr bool LASTQ = SMRF_FUSED_LASTQ(T, R);
+  constexpr int KQ = (2 * R + ROWS - 1) / ROWS;          // the batch that staged a row this batch opens: KQ (or KQ - 1) back
+  T2 dq[LASTQ ? KQ : 1][NP];                             // the lane's own column of batches b - KQ .. b - 1
+#pragma unroll
+  for (int s = 0; s < (LASTQ ? KQ : 1); ++s)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { dq[s][p].x = T(0); dq[s][p].y = T(0); }
 
   prefetch();
   int par = 0;
@@ -172,7 +218,29 @@ void fused_open_kernel(const DiskArgs<T> a) {
     phase_sync();
     if (yy0 > ystart) epilogue(yy0 - ROWS);                // stores older than the loads issued next
     if (yy0 + ROWS < ye + 2 * R) prefetch();
-    load_last(yy0);
+    if constexpr (LASTQ) {
+      // opened row yy0 - 2R + i is input row e = i - 2R + KQ * ROWS of the batches since b - KQ: slot e / ROWS (slot KQ =
+      // this batch, whose own-column cells are staged at tid + R), row e % ROWS of it
+      T2 own[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+        own[p] = lds_read2<0>((unsigned)(size_t)(__attribute__((address_space(3))) void*)(LE + (p * NLEV + par) * WP + tid + R), T());
+      lds_wait<0>();
+#pragma unroll
+      for (int i = 0; i < ROWS; ++i) {
+        const int e = i - 2 * R + KQ * ROWS, slot = e / ROWS, w = e % ROWS;
+        const T2 src = slot < KQ ? dq[slot < KQ ? slot : 0][w / 2] : own[w / 2];
+        lastv[i] = (w & 1) ? src.y : src.x;
+      }
+#pragma unroll
+      for (int sl = 0; sl + 1 < KQ; ++sl)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) dq[sl][p] = dq[sl + 1][p];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) dq[KQ - 1][p] = own[p];
+    } else {
+      load_last(yy0);
+    }
     ring_build_consume<T, R, false, TW, NP, NPOS, 0>(LE, par, tid, has_last, v, accE, outvE, phase_sync);
     // ---- dilation stage: the eroded rows are its level 0 (cell R + tid), build, consume -> opened rows yy0 - 2R ...
 #pragma unroll

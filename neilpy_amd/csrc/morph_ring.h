@@ -87,6 +87,24 @@
 #ifndef SMRF_RING_BAL
 #define SMRF_RING_BAL 1
 #endif
+// second half of the ring updated in place (RingCfg::INPLACE): per radius from ring_inpl.inc, or everywhere / nowhere in
+// tuning builds; SLACK: registers added to the kernel's demand estimate (tuning the occupancy step it is built for)
+#ifndef SMRF_RING_INPLACE
+#define SMRF_RING_INPLACE(T, R) ring_tuned_inplace<T>(R)
+#endif
+#ifndef SMRF_RING_BASE_PB
+#define SMRF_RING_BASE_PB(T, R) 0   // 0: the default of RingCfg::BASE_PB
+#endif
+#ifndef SMRF_RING_INPLACE_SLACK
+#define SMRF_RING_INPLACE_SLACK 0
+#endif
+// in-place kernels: waves per SIMD they are built for and most row pairs per batch (per radius from ring_inpl.inc)
+#ifndef SMRF_RING_INPLACE_OCC
+#define SMRF_RING_INPLACE_OCC(T, R) ring_tuned_inplace_occ<T>(R)
+#endif
+#ifndef SMRF_RING_INPLACE_NP
+#define SMRF_RING_INPLACE_NP(T, R) ring_tuned_inplace_np<T>(R)
+#endif
 #ifndef SMRF_FORCE_OCC
 #define SMRF_OCC_OVERRIDE(...) __VA_ARGS__
 #else
@@ -104,6 +122,7 @@ constexpr int ring_occ_drop(int occ, int steps) {
 #include "ring_tune.inc"
 #include "ring_bal.inc"
 #include "ring_inc.inc"
+#include "ring_inpl.inc"
 
 // columns per workgroup per radius: 256 everywhere (512-column workgroups, one per CU, measured within +-1 % of 256 at
 // R >= 39 and 20-25 % slower below: gpurun_out/r02/probe_tw512.log)
@@ -182,6 +201,16 @@ __device__ __forceinline__ float op3(float a, float b, float c) {
 }
 template <bool DIL>
 __device__ __forceinline__ double op3(double a, double b, double c) { return op2<DIL>(op2<DIL>(a, b), c); }
+
+// acc = op(acc, b, c) with the accumulator TIED to one register (the in-place half of the ring: left to itself the
+// register allocator writes every result to a fresh register and keeps the ring sliding through the spare ones)
+template <bool DIL>
+__device__ __forceinline__ void op3_acc(float& acc, float b, float c) {
+  if constexpr (DIL) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(acc) : "v"(b), "v"(c));
+  else asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(acc) : "v"(b), "v"(c));
+}
+template <bool DIL>
+__device__ __forceinline__ void op3_acc(double& acc, double b, double c) { acc = op2<DIL>(op2<DIL>(acc, b), c); }
 
 // One LDS read of a {row A, row B} cell at byte address `addr + OFF`.  Written as asm so that
 // hipcc cannot fuse two of them into ds_read2_b64, which moves half the bytes per LDS cycle of
@@ -299,7 +328,15 @@ struct RingCfg {
   static constexpr int G = SMRF_RING_G(E * (2 * R + 2 * S::K));   // window lookups per pipelined group
   static constexpr int NG = (S::K - 1 + G - 1) / G;      // groups for k = 1..K-1
   static constexpr int gsize(int g) { int n = S::K - 1 - g * G; return n < 0 ? 0 : (n > G ? G : n); }
-  static constexpr int NEED_BASE = E * (2 * R + 2 * S::K + 20 + 4 * G) + 16;   // measured VGPR demand at D = 2
+  // INPLACE (round 3): the ring's second half (slots R-1 .. 2R-1, output rows below the input row) is updated IN PLACE,
+  // the slot <-> register mapping rotating by two per row pair (compile-time inside a batch) and one register rotation
+  // per batch, so that BOTH halves consume the window widths in the ascending order the lookups produce them and
+  // only the last few widths stay live (about 2K - 2G registers less than the shifting second half, which walks the
+  // widths downwards and so keeps all K of both rows until the end of the pair).  See ring_consume_inplace.
+  static constexpr bool INPLACE = INC && SMRF_RING_INPLACE(T, R);
+  static constexpr int BASE_PB = SMRF_RING_BASE_PB(T, R) > 0 ? SMRF_RING_BASE_PB(T, R) : INPLACE ? 1 : 8;   // row pairs per round trip of the base-level build (in-place kernels are built for registers)
+  static constexpr int NEED_BASE = INPLACE ? E * (2 * R + 2 * (G + 2) + 3 + 20 + 4 * G) + 16 + SMRF_RING_INPLACE_SLACK
+                                           : E * (2 * R + 2 * S::K + 20 + 4 * G) + 16;   // measured VGPR demand at D = 2
   static constexpr int D = SMRF_RING_DEPTH(NEED_BASE);   // lookup groups kept in flight
   static constexpr int greads(int g) {                   // LDS reads of lookup group g
     int n = 0;
@@ -313,7 +350,8 @@ struct RingCfg {
   }
   static constexpr int NEED = NEED_BASE + (D - 2) * 4 * G * E;
   static constexpr int OCC_EST = NEED <= 64 ? 8 : NEED <= 96 ? 5 : NEED <= 128 ? 4 : NEED <= 168 ? 3 : NEED <= 264 ? 2 : 1;
-  static constexpr int OCC_REG = ring_occ_drop(OCC_EST, ring_tuned_occ_drop<T>(R));
+  static constexpr int OCC_REG = INPLACE && SMRF_RING_INPLACE_OCC(T, R) > 0 ? SMRF_RING_INPLACE_OCC(T, R)
+                                                                          : ring_occ_drop(OCC_EST, ring_tuned_occ_drop<T>(R));
   static constexpr int WAVES = TW / 64;                  // waves per workgroup
   static constexpr int WG_LDS = (int)(160 * 1024 / LDS_BYTES) < 1 ? 1 : (int)(160 * 1024 / LDS_BYTES);
   static constexpr int OCC_LDS = WG_LDS * WAVES / 4 < 1 ? 1 : WG_LDS * WAVES / 4;
@@ -335,8 +373,9 @@ struct RingCfg {
 // the three barriers and the table build's latency over more output rows.
 template <typename T, int R, int TW>
 constexpr int ring_np() {
-  constexpr int mx = sizeof(T) == 4 ? ring_tuned_np_max<T>(R) : (ring_tuned_np_max<T>(R) / 2 < 1 ? 1 : ring_tuned_np_max<T>(R) / 2);
   using C1 = RingCfg<T, R, TW, 1>;
+  constexpr int mx = C1::INPLACE && SMRF_RING_INPLACE_NP(T, R) > 0 ? SMRF_RING_INPLACE_NP(T, R)
+                     : sizeof(T) == 4 ? ring_tuned_np_max<T>(R) : (ring_tuned_np_max<T>(R) / 2 < 1 ? 1 : ring_tuned_np_max<T>(R) / 2);
   constexpr int want = C1::OCC_REG * 4 / C1::WAVES < 1 ? 1 : C1::OCC_REG * 4 / C1::WAVES;   // workgroups per CU
   if constexpr (mx >= 4) if (RingCfg<T, R, TW, 4>::WG_LDS >= want) return 4;
   if constexpr (mx >= 3) if (RingCfg<T, R, TW, 3>::WG_LDS >= want) return 3;
@@ -345,6 +384,31 @@ constexpr int ring_np() {
 }
 #define SMRF_RING_NP(T, R) ring_np<T, R, SMRF_RING_TW_OF(T, R)>()
 
+
+// A completed output cell.  nt: as a non-temporal (streaming) store - the output plane is not read again before the
+// next launch, and kept out of the L2 it leaves the lines the kernels DO re-read there (the ring kernels share 2R halo
+// columns between neighbouring strips).  Measured on the 16384^2 benchmark: -1.7 % on the whole call, -3...-8 % on the
+// memory-bound windows; on a 4096^2 raster (64 MB planes, which the 256 MB infinity cache hands to the next launch)
+// +2 %, so the host sets DiskArgs::nt by plane size (morph.hip).
+template <typename T>
+__device__ __forceinline__ void smrf_store_out(T* p, T v, int nt) {
+  if (nt) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+// the flag step of one output cell (neilpy.py:1671-1674): sparse (only flagged cells are written, the planes were
+// cleared) or dense (every byte written: the first window of a call, whose planes then need no clearing)
+template <typename T>
+__device__ __forceinline__ void smrf_flag_cell(const DiskArgs<T>& a, long long off, T lastval, T val) {
+  const T diff = lastval - val;                            // raster dtype
+  const bool hit = (double)diff > a.thr;                   // float64 comparison (NumPy 2)
+  if (a.dense) {
+    a.mask[off] = hit ? 1 : 0;
+    if (a.when != nullptr) a.when[off] = hit ? (uint8_t)a.widx : (uint8_t)0;
+  } else if (hit) {
+    a.mask[off] = 1;
+    if (a.when != nullptr) a.when[off] = (uint8_t)a.widx;
+  }
+}
 
 // reflect-folded local row index of consecutive global rows without a division per row
 struct RowFold {
@@ -384,21 +448,26 @@ __device__ __forceinline__ void ring_base(typename Vec2<T>::type* const L, const
   //     ds_read2_b64), then one wait, then the min/max and the writes.
   constexpr int NA = (1 << JB) - 1;
   const unsigned lds_l = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(L + tid + OFF);
+  // PB row pairs per round trip: all NP of them (one wait per cell position) unless the kernel is built for registers
+  // (RingCfg::BASE_PB: the reads of a round trip are 2 * NA registers per pair)
+  constexpr int PB = C::BASE_PB < NP ? C::BASE_PB : NP;
 #pragma unroll
   for (int i = 0; i < NPB; ++i) {
     if (i < NPB - 1 || has_last) {
+     const int pos = tid + OFF + i * TW;
+#pragma unroll
+     for (int p0 = 0; p0 < NP; p0 += PB) {
       T2 na[NP][NA];
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
+      for (int p = p0; p < p0 + PB && p < NP; ++p) {
         const unsigned ad = lds_l + ((p * NLEV + par) * WP + i * TW) * (unsigned)sizeof(T2);
         [&]<int... Kk>(std::integer_sequence<int, Kk...>) {
           ((na[p][Kk] = lds_read2<(Kk + 1) * (int)sizeof(T2)>(ad, T())), ...);
         }(std::make_integer_sequence<int, NA>{});
       }
       lds_wait<0>();
-      const int pos = tid + OFF + i * TW;
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
+      for (int p = p0; p < p0 + PB && p < NP; ++p) {
         const T2* n = na[p];
         T2 m = v[p][i];
         if constexpr (C::INC) {
@@ -428,6 +497,7 @@ __device__ __forceinline__ void ring_base(typename Vec2<T>::type* const L, const
         L[(p * NLEV + SB) * WP + pos] = m;
       }
       __builtin_amdgcn_sched_barrier(0);
+     }
     }
   }
 }
@@ -629,11 +699,19 @@ __device__ __forceinline__ void ring_upper_halo(typename Vec2<T>::type* const L,
 }
 
 template <typename T, int R, bool DIL, int TW, int NP>
+__device__ __forceinline__ void ring_consume_inplace(typename Vec2<T>::type* const L, const int par, const int tid,
+                                                     T (&acc)[2 * R], T (&outv)[2 * NP]);
+
+template <typename T, int R, bool DIL, int TW, int NP>
 __device__ __forceinline__ void ring_consume(typename Vec2<T>::type* const L, const int par, const int tid, T (&acc)[2 * R],
                                              T (&outv)[2 * NP]) {
   using C = RingCfg<T, R, TW, NP>;
   using S = typename C::S;
   using T2 = typename Vec2<T>::type;
+  if constexpr (C::INPLACE) {
+    ring_consume_inplace<T, R, DIL, TW, NP>(L, par, tid, acc, outv);
+    return;
+  }
   constexpr int K = S::K, WP = C::WP, G = C::G, NG = C::NG, NLEV = C::NLEV, D = C::D;
   constexpr int KR1 = S::kidx(R - 1);                   // width index of dy = +-(R-1)
   const unsigned lds_q = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(L + tid + R);
@@ -748,6 +826,137 @@ __device__ __forceinline__ void ring_consume(typename Vec2<T>::type* const L, co
     acc[2 * R - 1] = rb[0];
     __builtin_amdgcn_sched_barrier(0);
   }
+  }
+}
+
+// ring_consume with the second half of the ring updated in place (RingCfg::INPLACE).
+//   acc[0 .. R-2]      first half F, shifting as in ring_consume: F[s] = op3(F[s+2], RA[kA(s)], RB[kB(s)]), s ascending,
+//                      i.e. widths ascending
+//   acc[R-1 .. 2R-1]   second half B as a register ring of M = R + 1: logical slot j = s - (R - 1) of pair P (P-th pair of
+//                      the batch) lives in acc[R - 1 + (j + 2P) % M].  The pair's update B'[j] = op3(B[j+2], RA[kidx(j+1)],
+//                      RB[kidx(j)]) overwrites the register of B[j+2] - which IS the register of B'[j] under the next
+//                      pair's mapping - so the slots can be taken in any order: j descending = widths ascending, each as
+//                      soon as its lookup group is reduced.  B[0], B[1] are only read (by F[R-3], F[R-2], last) and then
+//                      take the pair's two new-born slots.  After the batch's NP pairs the mapping is turned back by
+//                      2 NP registers (M v_mov per batch, 2.1 cycles each against 4.1 for the min/max they sit beside).
+template <typename T, int R, bool DIL, int TW, int NP>
+__device__ __forceinline__ void ring_consume_inplace(typename Vec2<T>::type* const L, const int par, const int tid,
+                                                     T (&acc)[2 * R], T (&outv)[2 * NP]) {
+  using C = RingCfg<T, R, TW, NP>;
+  using S = typename C::S;
+  using T2 = typename Vec2<T>::type;
+  static_assert(C::INC && R >= 4, "in-place ring: incremental widths, R >= 4");
+  constexpr int K = S::K, WP = C::WP, G = C::G, NG = C::NG, NLEV = C::NLEV, D = C::D;
+  constexpr int KR1 = S::kidx(R - 1);
+  constexpr int M = R + 1;
+  const unsigned lds_q = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(L + tid + R);
+  T2 own[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+    own[p] = lds_read2<0>(lds_q + (p * NLEV + par) * WP * (unsigned)sizeof(T2), T());
+  lds_wait<0>();
+  auto pair_body = [&]<int P>(std::integral_constant<int, P>) {
+    const unsigned q = lds_q + P * NLEV * WP * (unsigned)sizeof(T2);
+    __builtin_amdgcn_s_setprio(SMRF_RING_LOOKUP_PRIO);
+    T ra[K], rb[K];
+    T2 ta[D][G], tb[D][G], tc[D][G], td[D][G];
+    const unsigned q0 = q + (unsigned)par * (unsigned)(WP * sizeof(T2)) - (unsigned)(R * sizeof(T2));
+    auto issue = [&]<int GI>(std::integral_constant<int, GI>) {
+      [&]<int... I>(std::integer_sequence<int, I...>) {
+        (([&] {
+           constexpr int k = 1 + GI * G + I;
+           if constexpr (k < K) {
+             constexpr int w = S::wk(k);
+             constexpr int j = C::inc_lev(k);
+             static_assert(C::stored(j), "step level not built");
+             static_assert(C::inc_n(k) <= 2, "width step longer than two table entries");
+             constexpr int base = j == 0 ? R : C::slot_of(j) * WP;
+             const unsigned qq = j == 0 ? q0 : q;
+             ta[GI % D][I] = lds_read2<(base - w) * (int)sizeof(T2)>(qq, T());
+             tb[GI % D][I] = lds_read2<(base + w - (1 << j) + 1) * (int)sizeof(T2)>(qq, T());
+             if constexpr (C::inc_n(k) == 2) {
+               tc[GI % D][I] = lds_read2<(base - w + (1 << j)) * (int)sizeof(T2)>(qq, T());
+               td[GI % D][I] = lds_read2<(base + w - (2 << j) + 1) * (int)sizeof(T2)>(qq, T());
+             }
+           }
+         }()), ...);
+      }(std::make_integer_sequence<int, G>{});
+    };
+    auto reduce = [&]<int GI>(std::integral_constant<int, GI>) {
+      [&]<int... I>(std::integer_sequence<int, I...>) {
+        (([&] {
+           constexpr int k = 1 + GI * G + I;
+           if constexpr (k < K) {
+             T a = op3<DIL>(ra[k - 1], ta[GI % D][I].x, tb[GI % D][I].x);
+             T b = op3<DIL>(rb[k - 1], ta[GI % D][I].y, tb[GI % D][I].y);
+             if constexpr (C::inc_n(k) == 2) {
+               a = op3<DIL>(a, tc[GI % D][I].x, td[GI % D][I].x);
+               b = op3<DIL>(b, tc[GI % D][I].y, td[GI % D][I].y);
+             }
+             ra[k] = a;
+             rb[k] = b;
+           }
+         }()), ...);
+      }(std::make_integer_sequence<int, G>{});
+    };
+    // (k - 1) / G: the lookup group that completes width index k >= 1
+    auto slots = [&]<int GI>(std::integral_constant<int, GI>) {
+      // first half, s = 0 .. R-2, ascending (F[R-3], F[R-2] take their shifted-in value from B[0], B[1])
+      [&]<int... Sl>(std::integer_sequence<int, Sl...>) {
+        (([&] {
+           constexpr int ka = C::kA(Sl), kb = C::kB(Sl);       // ka >= kb >= 0, ka >= 1
+           if constexpr ((ka - 1) / G == GI) {
+             constexpr int src = Sl + 2 <= R - 2 ? Sl + 2 : R - 1 + ((Sl + 2 - (R - 1)) + 2 * P) % M;
+             acc[Sl] = op3<DIL>(acc[src], ra[ka], rb[kb]);
+           }
+         }()), ...);
+      }(std::make_integer_sequence<int, R - 1>{});
+      // second half in place, logical j = R-2 .. 0 (widths ascending): B'[j] = op3(B[j+2], RA[kidx(j+1)], RB[kidx(j)])
+      [&]<int... Jr>(std::integer_sequence<int, Jr...>) {
+        (([&] {
+           constexpr int j = R - 2 - Jr;
+           constexpr int ka = S::kidx(j + 1), kb = S::kidx(j);   // kb >= ka
+           if constexpr ((kb - 1) / G == GI) {
+             constexpr int reg = R - 1 + (j + 2 + 2 * P) % M;
+             op3_acc<DIL>(acc[reg], ra[ka], rb[kb]);
+           }
+         }()), ...);
+      }(std::make_integer_sequence<int, R - 1>{});
+    };
+    [&]<int... GI>(std::integer_sequence<int, GI...>) {   // prologue: the first D-1 groups
+      (([&] { if constexpr (GI < NG) issue(std::integral_constant<int, GI>{}); }()), ...);
+    }(std::make_integer_sequence<int, D - 1>{});
+    ra[0] = own[P].x;
+    rb[0] = own[P].y;
+    outv[2 * P] = op2<DIL>(acc[0], ra[0]);
+    [&]<int... GI>(std::integer_sequence<int, GI...>) {
+      (([&] {
+         if constexpr (GI + D - 1 < NG) issue(std::integral_constant<int, GI + D - 1>{});
+         lds_wait<C::inflight_after(GI)>();
+         reduce(std::integral_constant<int, GI>{});
+         if constexpr (GI == (KR1 - 1) / G) outv[2 * P + 1] = op3<DIL>(acc[1], ra[KR1], rb[0]);   // before F[1] is overwritten
+         if constexpr (GI == NG - 1) __builtin_amdgcn_s_setprio(0);
+         slots(std::integral_constant<int, GI>{});
+       }()), ...);
+    }(std::make_integer_sequence<int, NG>{});
+    // the pair's two new-born slots (logical R-1, R of the next pair's mapping) take the registers of B[0], B[1]
+    acc[R - 1 + (2 * P) % M] = op2<DIL>(ra[0], rb[KR1]);
+    acc[R - 1 + (1 + 2 * P) % M] = rb[0];
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  [&]<int... P>(std::integer_sequence<int, P...>) {
+    (pair_body(std::integral_constant<int, P>{}), ...);
+  }(std::make_integer_sequence<int, NP>{});
+  // turn the mapping back: logical j sits in B[(j + 2 NP) % M]
+  {
+    constexpr int ROT = (2 * NP) % M;
+    if constexpr (ROT != 0) {
+      T t[M];
+#pragma unroll
+      for (int i = 0; i < M; ++i) t[i] = acc[R - 1 + (i + ROT) % M];
+#pragma unroll
+      for (int i = 0; i < M; ++i) acc[R - 1 + i] = t[i];
+    }
   }
 }
 
@@ -890,7 +1099,7 @@ void ring_kernel(const DiskArgs<T> a) {
     }
     rf.advance(ROWS);
   };
-  // one completed output cell: NaN rule, store, flag step
+  // one completed output cell, general form: NaN rule, store, flag step (sparse or dense)
   auto emit = [&](int yo, long long off, T val, T lastval) {
     if (a.nan_aware) {
       // scipy: the first visited footprint element (offset (-R, 0)) decides NaN-ness
@@ -898,12 +1107,24 @@ void ring_kernel(const DiskArgs<T> a) {
       const T first = a.in[(long long)ly * a.ld + x];
       if (first != first) val = qnan<T>();
     }
-    a.out[off] = val;
-    if (flag) {
-      const T diff = lastval - val;                        // raster dtype
-      if ((double)diff > a.thr) {                          // float64 comparison (NumPy 2)
-        a.mask[off] = 1;
-        if (a.when != nullptr) a.when[off] = (uint8_t)a.widx;
+    smrf_store_out(&a.out[off], val, a.nt);
+    if (flag) smrf_flag_cell(a, off, lastval, val);
+  };
+  // the common case of a batch (all ROWS rows inside the segment, no NaN rule, sparse flags) as straight-line code per
+  // (store kind, flag step): the uniform tests are made once per batch, not once per cell - scalar branches between
+  // the VALU instructions of a kernel that runs at 2-3 waves per SIMD are not free (profiles/r02_issue_rate_ubench.md)
+  auto emit_rows = [&]<bool NT, bool FLAG>(std::bool_constant<NT>, std::bool_constant<FLAG>, long long off0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      const long long off = off0 + (long long)i * a.ld;
+      if constexpr (NT) __builtin_nontemporal_store(outv[i], &a.out[off]);
+      else a.out[off] = outv[i];
+      if constexpr (FLAG) {
+        const T diff = lastv[i] - outv[i];                   // raster dtype
+        if ((double)diff > a.thr) {                          // float64 comparison (NumPy 2)
+          a.mask[off] = 1;
+          if (a.when != nullptr) a.when[off] = (uint8_t)a.widx;
+        }
       }
     }
   };
@@ -913,9 +1134,14 @@ void ring_kernel(const DiskArgs<T> a) {
     const int yob = yyb - R;                               // first output row of the batch
     if (yob < ys || x >= a.cols) return;                   // (aligned: yob < ys means all rows are)
     const long long off0 = (long long)(yob - a.out_row0) * a.ld + x;
-    if (yob + ROWS <= ye) {
-#pragma unroll
-      for (int i = 0; i < ROWS; ++i) emit(yob + i, off0 + (long long)i * a.ld, outv[i], lastv[i]);
+    if (yob + ROWS <= ye && !a.nan_aware && !a.dense) {
+      if (flag) {
+        if (a.nt) emit_rows(std::true_type{}, std::true_type{}, off0);
+        else emit_rows(std::false_type{}, std::true_type{}, off0);
+      } else {
+        if (a.nt) emit_rows(std::true_type{}, std::false_type{}, off0);
+        else emit_rows(std::false_type{}, std::false_type{}, off0);
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < ROWS; ++i)

@@ -58,6 +58,8 @@ struct DiskArgs {
   int radius;
   int nan_aware;
   int seg;            // output rows per workgroup (ring kernels)
+  int nt;             // output cells as non-temporal (streaming) stores: planes far larger than the caches
+  int dense;          // flag step writes EVERY mask / when byte (0 included): the planes need no clearing first
 };
 
 // ring-kernel dispatchers, one per (dtype, radius % SMRF_RING_PARTS); defined in ring_part.hip.

@@ -193,8 +193,11 @@ def progressive_filter_sharded(Z_band, img_rows, windows, thresholds, *, rank=No
     st = state if state is not None else {}
     key = (nloc, cols, H, str(dt), str(dev))
     if st.get("key") != key:
+        keep = st.get("profile")
         st.clear()
         st["key"] = key
+        if keep:
+            st["profile"] = keep
         st["ext"] = [torch.empty((e1 - e0, cols), dtype=dt, device=dev) for _ in range(2)]
         st["ero"] = torch.empty((e1 - e0, cols), dtype=dt, device=dev)
         st["mask"] = torch.empty((e1 - e0, cols), dtype=torch.uint8, device=dev)

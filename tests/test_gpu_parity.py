@@ -354,7 +354,7 @@ def test_sharded_two_ranks_on_one_gpu(nz, tmp_path):
     j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
     assert j2["n_gpus"] == 2 and j1["config"]["object_cells"] == j2["config"]["object_cells"]
     # the N = 1 line: median step, per-class split priced at the bytes each class moves (nothing above the peak)
-    assert len(j1["step_ms"]) == 3 and abs(j1["ms_per_step"] - sorted(j1["step_ms"])[1]) < 1e-6
+    assert len(j1["step_ms"]) == 3 and abs(j1["ms_per_step"] - sorted(j1["step_ms"])[1]) < 2e-3
     cl = j1["roofline"]["classes"]
     assert sum(c["windows"] for c in cl.values()) == 12 and all(c["gbps"] < 8000.0 for c in cl.values())
     assert len(j1["roofline"]["window_ms"]) == 12
