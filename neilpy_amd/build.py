@@ -33,7 +33,7 @@ def hipcc():
 
 def units():
     """(object name, source, extra flags)"""
-    out = [(n + ".o", os.path.join(CSRC, n + ".hip"), []) for n in ("core", "morph", "grid", "springs", "fda", "tail", "spline")]
+    out = [(n + ".o", os.path.join(CSRC, n + ".hip"), []) for n in ("core", "morph", "chain", "grid", "springs", "fda", "tail", "spline")]
     for f64 in (0, 1):
         for p in range(RING_PARTS):
             out.append(("ring_%s_p%d.o" % ("f64" if f64 else "f32", p), os.path.join(CSRC, "ring_part.hip"),

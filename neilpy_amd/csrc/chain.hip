@@ -1,0 +1,55 @@
+// Instantiates the chained small-window kernels of morph_chain.h and matches window lists against them.
+#include <cmath>
+
+#include "morph_chain.h"
+
+namespace {
+
+struct Pattern { int n; int r[4]; };
+// the chains that exist, longest first per starting radius (NP row pairs per batch - SMRF_CHAIN_NP - and the occupancy the
+// kernel is built for are per pattern, below).  Measured against one fused launch per window on the 16384^2 benchmark
+// (gpurun_out/r03q/cnp.log): 1, 2, 3: 0.82 against 1.96 ms; 4, 5: 1.17 against 1.53; 6, 7: 1.39 against 1.70; a chain 8, 9
+// (172 registers, two workgroups per CU) takes 3.1 ms against 2.0 and does not exist.
+constexpr Pattern kPatterns[] = {{3, {1, 2, 3, 0}}, {2, {1, 2, 0, 0}}, {2, {2, 3, 0, 0}}, {2, {4, 5, 0, 0}},
+                                 {2, {6, 7, 0, 0}}};
+constexpr int kNPatterns = (int)(sizeof(kPatterns) / sizeof(kPatterns[0]));
+
+template <typename T>
+int launch(int pat, const ChainArgs<T>& a_in, hipStream_t s) {
+  ChainArgs<T> a = a_in;
+  for (int i = 0; i < 4; ++i) {                            // largest float <= thr (morph_chain.h, flag step)
+    float f = (float)a.thr[i];
+    if ((double)f > a.thr[i]) f = std::nextafterf(f, -INFINITY);
+    a.thr_lo[i] = f;
+  }
+  switch (pat) {
+    case 0: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 0), 4, 1, 2, 3, 0>(a, s);
+    case 1: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 1), 4, 1, 2, 0, 0>(a, s);
+    case 2: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 2), 4, 2, 3, 0, 0>(a, s);
+    case 3: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 3), 4, 4, 5, 0, 0>(a, s);
+    case 4: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 4), 3, 6, 7, 0, 0>(a, s);
+    default: return smrf_fail(SMRF_E_ARG, "unknown chain pattern %d", pat);
+  }
+}
+
+}  // namespace
+
+int smrf_chain_match(int elem_size, const int32_t* windows, int n) {
+  for (int p = 0; p < kNPatterns; ++p) {
+    if (kPatterns[p].n > n) continue;
+    if (elem_size == 8 && p != 1 && p != 2) continue;      // fp64: only the chains whose kernels hold their rings in registers
+    bool ok = true;
+    for (int i = 0; i < kPatterns[p].n; ++i) ok = ok && windows[i] == kPatterns[p].r[i];
+    if (ok) return p;
+  }
+  return -1;
+}
+int smrf_chain_length(int pat) { return pat >= 0 && pat < kNPatterns ? kPatterns[pat].n : 0; }
+int smrf_chain_halo(int pat) {
+  int s = 0;
+  if (pat >= 0 && pat < kNPatterns)
+    for (int i = 0; i < kPatterns[pat].n; ++i) s += 2 * kPatterns[pat].r[i];
+  return s;
+}
+int smrf_chain_f32(int pat, const ChainArgs<float>& a, hipStream_t s) { return launch<float>(pat, a, s); }
+int smrf_chain_f64(int pat, const ChainArgs<double>& a, hipStream_t s) { return launch<double>(pat, a, s); }

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "smrf_common.h"
+#include "morph_chain.h"
 
 namespace {
 
@@ -285,19 +286,47 @@ int progressive_filter_api(const T* Z, int rows, int cols, const int32_t* window
   };
   const T* last = Z;
   // small disks: opening + flag in ONE launch, the eroded surface never leaves the CU (morph_fused.h; 10 instead of
-  // 22 B/cell in fp32).  Not for rasters with NaNs (scipy's NaN rule lives in the two-pass kernels only).
-  // SMRF_FUSED: 0 = never, 1 = default rule, 2 = every radius that has a fused kernel whatever the raster size (tests)
+  // 22 B/cell in fp32), and runs of consecutive small windows (1, 2, 3 | 4, 5 | 6, 7 | 8, 9) as ONE launch that only
+  // reads the first window's input and writes the last window's opening (morph_chain.h).  Not for rasters with NaNs
+  // (scipy's NaN rule lives in the two-pass kernels only).
+  // SMRF_FUSED: 0 = never, 1 = default rule, 2 = every radius that has a fused kernel whatever the raster size (tests);
+  // SMRF_CHAIN: 0 = no chains (every window its own launch).
   const int fuse_mode = smrf_env_int("SMRF_FUSED", 1);
   const bool fuse_ok = !nan_aware && (impl == SMRF_IMPL_AUTO || impl == SMRF_IMPL_RING) && fuse_mode != 0;
-  for (int i = 0; i < nwin; ++i) {
+  const bool chain_ok = fuse_ok && smrf_env_int("SMRF_CHAIN", 1) != 0;
+  int flip = 0;                                          // which of the two opened planes the next launch writes
+  for (int i = 0; i < nwin;) {
     const int r = windows[i];
-    T* opened = O[i & 1];
+    T* opened = O[flip];
+    flip ^= 1;
+    const int pat = chain_ok ? smrf_chain_match((int)sizeof(T), windows + i, nwin - i) : -1;
+    if (pat >= 0 && smrf_chain_halo(pat) < rows) {
+      const int len = smrf_chain_length(pat);
+      ChainArgs<T> c{};
+      c.in = last; c.out = opened; c.mask = mask; c.when = when;
+      for (int k = 0; k < len; ++k) { c.thr[k] = thr[i + k]; c.widx[k] = i + k; }
+      c.img_rows = rows; c.cols = cols; c.ld = cols;
+      c.in_row0 = 0; c.in_rows = rows; c.out_row0 = 0; c.out_rows = rows;
+      c.seg = smrf_env_int("SMRF_RING_SEG", 0);
+      c.nt = nt_rule<T>(rows, cols);
+      c.dense0 = i == 0;
+      int crc;
+      if constexpr (sizeof(T) == 4) crc = smrf_chain_f32(pat, c, stream);
+      else crc = smrf_chain_f64(pat, c, stream);
+      if (crc) return crc;
+      if (nwin > 1) last = opened;
+      for (int k = 0; k < len; ++k)                        // the chain's time is recorded on its last window
+        if (int rc = window_done(i + k, SMRF_ROUTE_CHAIN + k)) return rc;
+      i += len;
+      continue;
+    }
     // above R = 8 the fused kernel's 4R warm-up rows per segment only pay on rasters large enough for long segments
     // (4096^2, windows 1..18: 1.64 ms with R <= 8 fused, 1.70 ms with 10..14 as well; 8192^2: 5.9 -> 5.2 ms with them)
     if (fuse_ok && smrf_fused_radius((int)sizeof(T), r) && (r <= 8 || fuse_mode == 2 || plane >= ((size_t)48 << 20))) {
       if (int rc = open_flag_api<T>(last, opened, mask, when, thr[i], i, rows, cols, cols, 0, rows, 0, rows, r, stream_, i == 0)) return rc;
       if (nwin > 1) last = opened;
       if (int rc = window_done(i, SMRF_ROUTE_FUSED)) return rc;
+      ++i;
       continue;
     }
     if (int rc = disk_filter_api<T>(last, E, rows, cols, cols, 0, rows, 0, rows, r, 0, nan_aware, impl, stream_)) return rc;
@@ -307,6 +336,7 @@ int progressive_filter_api(const T* Z, int rows, int cols, const int32_t* window
     if (nwin > 1) last = opened;                        // neilpy.py:1675-1676
     const int eff = impl == SMRF_IMPL_AUTO ? (r <= SMRF_RING_MAX_RADIUS ? SMRF_IMPL_RING : SMRF_IMPL_DIRECT) : impl;
     if (int rc = window_done(i, r == 0 ? SMRF_ROUTE_COPY : eff == SMRF_IMPL_RING ? SMRF_ROUTE_TWO_PASS : SMRF_ROUTE_DIRECT)) return rc;
+    ++i;
   }
   return finish();
 }
