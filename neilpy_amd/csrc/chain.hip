@@ -5,13 +5,18 @@
 
 namespace {
 
-struct Pattern { int n; int r[4]; };
-// the chains that exist, longest first per starting radius (NP row pairs per batch - SMRF_CHAIN_NP - and the occupancy the
-// kernel is built for are per pattern, below).  Measured against one fused launch per window on the 16384^2 benchmark
-// (gpurun_out/r03q/cnp.log): 1, 2, 3: 0.82 against 1.96 ms; 4, 5: 1.17 against 1.53; 6, 7: 1.39 against 1.70; a chain 8, 9
-// (172 registers, two workgroups per CU) takes 3.1 ms against 2.0 and does not exist.
-constexpr Pattern kPatterns[] = {{3, {1, 2, 3, 0}}, {2, {1, 2, 0, 0}}, {2, {2, 3, 0, 0}}, {2, {4, 5, 0, 0}},
-                                 {2, {6, 7, 0, 0}}};
+struct Pattern { int n; int r[4]; long long min_cells; };
+// The chains that exist, longest first per starting radius (NP row pairs per batch - SMRF_CHAIN_NP - and the occupancy the
+// kernel is built for are per pattern, below); a single window is a chain of one: the same table-free stages, which for
+// R = 8..10 beat the table-building fused kernel (and the two ring passes of R = 9).  min_cells: the smallest raster the
+// pattern is taken for (a chain's segments start sum(2R) rows early; on a 4096^2 raster 6, 7 and 9, 10 lose to one launch
+// per window).  Measured against one launch per window on the 16384^2 benchmark (gpurun_out/r03u/rounds3.log):
+// 1, 2, 3: 0.79 against 1.96 ms; 4, 5: 0.84 against 1.42; 6, 7: 1.28 against 1.52; 8: 0.65 against 0.84; 9: 0.72 against
+// 1.07; 10: 0.79 against 0.99; 11..14 lose (1.05 against 0.86 at 11), a chain 8, 9 (172 registers) 3.1 against 2.0.
+constexpr long long kLarge = 48ll << 20;
+constexpr Pattern kPatterns[] = {{3, {1, 2, 3, 0}, 0}, {2, {1, 2, 0, 0}, 0}, {2, {2, 3, 0, 0}, 0}, {2, {4, 5, 0, 0}, 0},
+                                 {2, {6, 7, 0, 0}, kLarge}, {1, {8, 0, 0, 0}, 0}, {1, {9, 0, 0, 0}, kLarge},
+                                 {1, {10, 0, 0, 0}, kLarge}};
 constexpr int kNPatterns = (int)(sizeof(kPatterns) / sizeof(kPatterns[0]));
 
 template <typename T>
@@ -28,15 +33,18 @@ int launch(int pat, const ChainArgs<T>& a_in, hipStream_t s) {
     case 2: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 2), 4, 2, 3, 0, 0>(a, s);
     case 3: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 3), 4, 4, 5, 0, 0>(a, s);
     case 4: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 4), 3, 6, 7, 0, 0>(a, s);
+    case 5: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 5), 4, 8, 0, 0, 0>(a, s);
+    case 6: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 6), 4, 9, 0, 0, 0>(a, s);
+    case 7: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 7), 4, 10, 0, 0, 0>(a, s);
     default: return smrf_fail(SMRF_E_ARG, "unknown chain pattern %d", pat);
   }
 }
 
 }  // namespace
 
-int smrf_chain_match(int elem_size, const int32_t* windows, int n) {
+int smrf_chain_match(int elem_size, const int32_t* windows, int n, long long cells) {
   for (int p = 0; p < kNPatterns; ++p) {
-    if (kPatterns[p].n > n) continue;
+    if (kPatterns[p].n > n || cells < kPatterns[p].min_cells) continue;
     if (elem_size == 8 && p != 1 && p != 2) continue;      // fp64: only the chains whose kernels hold their rings in registers
     bool ok = true;
     for (int i = 0; i < kPatterns[p].n; ++i) ok = ok && windows[i] == kPatterns[p].r[i];

@@ -299,7 +299,7 @@ int progressive_filter_api(const T* Z, int rows, int cols, const int32_t* window
     const int r = windows[i];
     T* opened = O[flip];
     flip ^= 1;
-    const int pat = chain_ok ? smrf_chain_match((int)sizeof(T), windows + i, nwin - i) : -1;
+    const int pat = chain_ok ? smrf_chain_match((int)sizeof(T), windows + i, nwin - i, fuse_mode == 2 ? (1ll << 62) : (long long)plane) : -1;
     if (pat >= 0 && smrf_chain_halo(pat) < rows) {
       const int len = smrf_chain_length(pat);
       ChainArgs<T> c{};

@@ -48,7 +48,7 @@ struct ChainArgs {
 };
 
 // chain dispatch (chain.hip): the pattern a window list starts with (-1: none), its length and halo rows, the launch
-SMRF_HIDDEN int smrf_chain_match(int elem_size, const int32_t* windows, int n);
+SMRF_HIDDEN int smrf_chain_match(int elem_size, const int32_t* windows, int n, long long cells);
 SMRF_HIDDEN int smrf_chain_length(int pattern);
 SMRF_HIDDEN int smrf_chain_halo(int pattern);
 SMRF_HIDDEN int smrf_chain_f32(int pattern, const ChainArgs<float>& a, hipStream_t s);
@@ -367,8 +367,11 @@ int chain_launch(const ChainArgs<T>& a_in, hipStream_t stream) {
   ChainArgs<T> a = a_in;
   const int strips = (a.cols + C::TWO - 1) / C::TWO;
   if (a.seg <= 0) {
-    const int rounds = smrf_env_int("SMRF_CHAIN_ROUNDS", 1);
-    const int nseg = std::max(1, (rounds * resident * 256 + strips / 2) / strips);   // every workgroup resident at once
+    // three workgroups per resident slot: the workgroups a CU really holds can be fewer than the occupancy query says
+    // (chain 4, 5: 2.4 waves per SIMD measured where 4 were expected), and a launch sized for exactly one round then
+    // runs a second, mostly empty one; with three the tail is short whatever the residency (chain 4, 5: 1.17 -> 0.87 ms)
+    const int rounds = smrf_env_int("SMRF_CHAIN_ROUNDS", 3);
+    const int nseg = std::max(1, (rounds * resident * 256 + strips / 2) / strips);
     int seg = (a.out_rows + nseg - 1) / nseg;
     seg = std::max(seg, std::max(32, 4 * C::S));           // a segment re-reads 2S warm-up rows
     seg = std::min(seg, a.out_rows);

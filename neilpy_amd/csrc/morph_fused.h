@@ -287,7 +287,8 @@ int fused_launch(const DiskArgs<T>& a_in, hipStream_t stream) {
   constexpr int TWO = TW - 2 * R;
   const int strips = (a.cols + TWO - 1) / TWO;
   if (a.seg <= 0) {
-    const int nseg = std::max(1, (resident * 256 + strips / 2) / strips);   // one round: every workgroup resident
+    const int rounds = smrf_env_int("SMRF_FUSED_ROUNDS", 1);
+    const int nseg = std::max(1, (rounds * resident * 256 + strips / 2) / strips);   // one round: every workgroup resident
     int seg = (a.out_rows + nseg - 1) / nseg;
     seg = std::max(seg, std::max(32, 8 * R));             // a segment re-reads 4R warm-up rows
     seg = std::min(seg, a.out_rows);

@@ -44,13 +44,16 @@ def w50(which, nz):
     return g, Z
 
 
-@pytest.mark.parametrize("fused", [None, "0", "2"])
-def test_w50_mid_reference_golden(nz, monkeypatch, fused):
-    """default routing, two-pass everywhere (SMRF_FUSED=0), fused wherever a fused kernel exists (SMRF_FUSED=2)"""
-    if fused is None:
-        monkeypatch.delenv("SMRF_FUSED", raising=False)
-    else:
-        monkeypatch.setenv("SMRF_FUSED", fused)
+@pytest.mark.parametrize("fused,chain", [(None, None), ("0", None), ("2", None), ("2", "0"), (None, "0")])
+def test_w50_mid_reference_golden(nz, monkeypatch, fused, chain):
+    """default routing (chained small windows, fused, two-pass), two-pass everywhere (SMRF_FUSED=0), every chain / fused
+    kernel that exists whatever the raster size (SMRF_FUSED=2), the same without chains (SMRF_CHAIN=0: every small window
+    through its own fused launch)"""
+    for name, val in (("SMRF_FUSED", fused), ("SMRF_CHAIN", chain)):
+        if val is None:
+            monkeypatch.delenv(name, raising=False)
+        else:
+            monkeypatch.setenv(name, val)
     g, Z = w50("mid", nz)
     windows = g["windows"]
     assert list(windows) == list(range(1, 51))
