@@ -123,6 +123,7 @@ constexpr int ring_occ_drop(int occ, int steps) {
 #include "ring_bal.inc"
 #include "ring_inc.inc"
 #include "ring_inpl.inc"
+#include "ring_buf.inc"
 
 // columns per workgroup per radius: 256 everywhere (512-column workgroups, one per CU, measured within +-1 % of 256 at
 // R >= 39 and 20-25 % slower below: gpurun_out/r02/probe_tw512.log)
@@ -384,6 +385,36 @@ constexpr int ring_np() {
 }
 #define SMRF_RING_NP(T, R) ring_np<T, R, SMRF_RING_TW_OF(T, R)>()
 
+
+// Buffer addressing (SMRF_RING_BUF): the common-case loads and stores of the ring kernel as buffer instructions - a
+// resource descriptor in 4 SGPRs per plane (based at the first row the workgroup touches), the row as a scalar byte
+// offset, the lane's column as one 32-bit VGPR offset computed once - instead of a 64-bit address per lane and access
+// (v_lshl_add_u64, 4.1 cycles each, ~40 per batch in round 2's kernels, and a VGPR pair each while in flight).
+#ifndef SMRF_RING_BUF
+#define SMRF_RING_BUF(T, R) ring_tuned_buf<T>(R)
+#endif
+using smrf_rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ smrf_rsrc_t smrf_make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ float smrf_buf_load(smrf_rsrc_t r, unsigned voff, unsigned soff, float) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ double smrf_buf_load(smrf_rsrc_t r, unsigned voff, unsigned soff, double) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+}
+template <bool NT>
+__device__ __forceinline__ void smrf_buf_store(smrf_rsrc_t r, unsigned voff, unsigned soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, NT ? 2 : 0);
+}
+template <bool NT>
+__device__ __forceinline__ void smrf_buf_store(smrf_rsrc_t r, unsigned voff, unsigned soff, double v) {
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), r, (int)voff, (int)soff, NT ? 2 : 0);
+}
+__device__ __forceinline__ void smrf_buf_store_u8(smrf_rsrc_t r, unsigned voff, unsigned soff, uint8_t v) {
+  __builtin_amdgcn_raw_buffer_store_b8(v, r, (int)voff, (int)soff, 0);
+}
 
 // A completed output cell.  nt: as a non-temporal (streaming) store - the output plane is not read again before the
 // next launch, and kept out of the L2 it leaves the lines the kernels DO re-read there (the ring kernels share 2R halo
@@ -1049,10 +1080,51 @@ void ring_kernel(const DiskArgs<T> a) {
   constexpr int DELTA = (ROWS - (2 * R) % ROWS) % ROWS;
   const int ystart = ys - R - DELTA;
   RowFold rf(ystart, a.img_rows);                        // tracks the NEXT batch to prefetch
+  // buffer addressing of the common cases (SMRF_RING_BUF): descriptors based at the first row of each plane this
+  // workgroup touches there, byte offsets of the lane's columns; the host keeps a segment's span below 4 GiB
+  constexpr bool BUF = SMRF_RING_BUF(T, R);
+  const int bi = max(0, ystart - a.in_row0);                       // first band row of `in` a fast-path batch can start at
+  const int bl = max(0, ys - 2 * R - DELTA - a.out_row0);          // ... of `last` (first batch: outputs of rows ystart - R ...)
+  const int bo = ys - a.out_row0;                                  // ... of `out`, `mask`, `when`
+  const unsigned rowb = (unsigned)a.ld * (unsigned)sizeof(T);     // bytes per row
+  // (descriptors of planes a launch does not have are built from null pointers and never used)
+  const smrf_rsrc_t rs_in = smrf_make_rsrc(a.in + (long long)bi * a.ld);
+  const smrf_rsrc_t rs_out = smrf_make_rsrc(a.out + (long long)bo * a.ld);
+  const smrf_rsrc_t rs_last = smrf_make_rsrc(flag ? a.last + (long long)bl * a.ld : nullptr);
+  const smrf_rsrc_t rs_mask = smrf_make_rsrc(flag ? a.mask + (long long)bo * a.ld : nullptr);
+  const smrf_rsrc_t rs_when = smrf_make_rsrc(flag && a.when != nullptr ? a.when + (long long)bo * a.ld : nullptr);
+  unsigned cposb[NPOS], hcolb = 0, xb = 0, xcb = 0;
+  if constexpr (BUF) {
+#pragma unroll
+    for (int i = 0; i < NPOS; ++i) cposb[i] = (unsigned)cpos[i] * (unsigned)sizeof(T);
+    hcolb = (unsigned)hcol * (unsigned)sizeof(T);
+    xb = (unsigned)x * (unsigned)sizeof(T);
+    xcb = (unsigned)xc * (unsigned)sizeof(T);
+  }
   auto prefetch = [&]() {
     const int l0 = rf.p - a.in_row0;
     if (rf.p + ROWS <= rf.n && l0 >= 0 && l0 + ROWS - 1 <= last_in) {
       // common case: ROWS consecutive rows inside the band, no reflection: one address, row strides
+      if constexpr (BUF) {
+        const unsigned s0 = (unsigned)(l0 - bi) * rowb;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+#pragma unroll
+          for (int i = 0; i < (BAL ? 1 : NPOS); ++i) {
+            pf[p][i].x = smrf_buf_load(rs_in, cposb[i], s0 + (unsigned)(2 * p) * rowb, T());
+            pf[p][i].y = smrf_buf_load(rs_in, cposb[i], s0 + (unsigned)(2 * p + 1) * rowb, T());
+          }
+        }
+        if constexpr (BAL) {
+#pragma unroll
+          for (int j = 0; j < H::NJ; ++j) {
+            const int q = hl.wave + H::WAVES * j;
+            const int pq = q < H::NQ ? q / H::NH : 0;
+            pfh[j].x = smrf_buf_load(rs_in, hcolb, s0 + (unsigned)(2 * pq) * rowb, T());
+            pfh[j].y = smrf_buf_load(rs_in, hcolb, s0 + (unsigned)(2 * pq + 1) * rowb, T());
+          }
+        }
+      } else {
       const T* r0 = a.in + (long long)l0 * a.ld;
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
@@ -1070,6 +1142,7 @@ void ring_kernel(const DiskArgs<T> a) {
           pfh[j].x = r0[(long long)(2 * pq) * a.ld + hcol];
           pfh[j].y = r0[(long long)(2 * pq + 1) * a.ld + hcol];
         }
+      }
       }
     } else {
 #pragma unroll
@@ -1113,17 +1186,25 @@ void ring_kernel(const DiskArgs<T> a) {
   // the common case of a batch (all ROWS rows inside the segment, no NaN rule, sparse flags) as straight-line code per
   // (store kind, flag step): the uniform tests are made once per batch, not once per cell - scalar branches between
   // the VALU instructions of a kernel that runs at 2-3 waves per SIMD are not free (profiles/r02_issue_rate_ubench.md)
-  auto emit_rows = [&]<bool NT, bool FLAG>(std::bool_constant<NT>, std::bool_constant<FLAG>, long long off0) __attribute__((always_inline)) {
+  auto emit_rows = [&]<bool NT, bool FLAG>(std::bool_constant<NT>, std::bool_constant<FLAG>, long long off0, int ro0) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
       const long long off = off0 + (long long)i * a.ld;
-      if constexpr (NT) __builtin_nontemporal_store(outv[i], &a.out[off]);
+      const unsigned so = (unsigned)(ro0 - bo + i) * rowb;   // BUF: row offset from the segment's first output row
+      if constexpr (BUF) smrf_buf_store<NT>(rs_out, xb, so, outv[i]);
+      else if constexpr (NT) __builtin_nontemporal_store(outv[i], &a.out[off]);
       else a.out[off] = outv[i];
       if constexpr (FLAG) {
         const T diff = lastv[i] - outv[i];                   // raster dtype
         if ((double)diff > a.thr) {                          // float64 comparison (NumPy 2)
-          a.mask[off] = 1;
-          if (a.when != nullptr) a.when[off] = (uint8_t)a.widx;
+          if constexpr (BUF) {
+            const unsigned sm = (unsigned)(ro0 - bo + i) * (unsigned)a.ld;
+            smrf_buf_store_u8(rs_mask, (unsigned)x, sm, (uint8_t)1);
+            if (a.when != nullptr) smrf_buf_store_u8(rs_when, (unsigned)x, sm, (uint8_t)a.widx);
+          } else {
+            a.mask[off] = 1;
+            if (a.when != nullptr) a.when[off] = (uint8_t)a.widx;
+          }
         }
       }
     }
@@ -1135,12 +1216,13 @@ void ring_kernel(const DiskArgs<T> a) {
     if (yob < ys || x >= a.cols) return;                   // (aligned: yob < ys means all rows are)
     const long long off0 = (long long)(yob - a.out_row0) * a.ld + x;
     if (yob + ROWS <= ye && !a.nan_aware && !a.dense) {
+      const int ro0 = yob - a.out_row0;
       if (flag) {
-        if (a.nt) emit_rows(std::true_type{}, std::true_type{}, off0);
-        else emit_rows(std::false_type{}, std::true_type{}, off0);
+        if (a.nt) emit_rows(std::true_type{}, std::true_type{}, off0, ro0);
+        else emit_rows(std::false_type{}, std::true_type{}, off0, ro0);
       } else {
-        if (a.nt) emit_rows(std::true_type{}, std::false_type{}, off0);
-        else emit_rows(std::false_type{}, std::false_type{}, off0);
+        if (a.nt) emit_rows(std::true_type{}, std::false_type{}, off0, ro0);
+        else emit_rows(std::false_type{}, std::false_type{}, off0, ro0);
       }
     } else {
 #pragma unroll
@@ -1152,9 +1234,15 @@ void ring_kernel(const DiskArgs<T> a) {
     if (!flag) return;
     const int y0 = yyb - R - a.out_row0;
     if (y0 >= 0 && y0 + ROWS <= a.out_rows) {
+      if constexpr (BUF) {
+        const unsigned s0 = (unsigned)(y0 - bl) * rowb;
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) lastv[i] = smrf_buf_load(rs_last, xcb, s0 + (unsigned)i * rowb, T());
+      } else {
       const T* l0 = a.last + (long long)y0 * a.ld + xc;
 #pragma unroll
       for (int i = 0; i < ROWS; ++i) lastv[i] = l0[(long long)i * a.ld];
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < ROWS; ++i) {
@@ -1261,6 +1349,14 @@ int ring_launch(const DiskArgs<T>& a_in, hipStream_t stream) {
     a.seg = seg;
   }
   a.seg = ((a.seg + C::ROWS - 1) / C::ROWS) * C::ROWS;
+  if constexpr (SMRF_RING_BUF(T, R)) {
+    // buffer addressing: a workgroup's row offsets are 32-bit (and not range-checked by the hardware): keep the span of
+    // a segment (its rows + warm-up + one batch) below 2 GiB
+    const long long rowb = (long long)a.ld * (long long)sizeof(T);
+    const long long max_rows = ((1ll << 31) - 1) / rowb - (4 * R + 4 * C::ROWS);
+    if (max_rows < C::ROWS) return smrf_fail(SMRF_E_UNSUPPORTED, "raster rows of %lld bytes are too long for this build", rowb);
+    if (a.seg > max_rows) a.seg = (int)(max_rows / C::ROWS) * C::ROWS;
+  }
   dim3 grid(strips, (a.out_rows + a.seg - 1) / a.seg);
   hipLaunchKernelGGL(kern, grid, dim3(TW), C::LDS_BYTES, stream, a);
   SMRF_LAUNCH_CHECK();
