@@ -23,9 +23,7 @@ template <typename T>
 int launch(int pat, const ChainArgs<T>& a_in, hipStream_t s) {
   ChainArgs<T> a = a_in;
   for (int i = 0; i < 4; ++i) {                            // largest float <= thr (morph_chain.h, flag step)
-    float f = (float)a.thr[i];
-    if ((double)f > a.thr[i]) f = std::nextafterf(f, -INFINITY);
-    a.thr_lo[i] = f;
+    a.thr_lo[i] = smrf_float_below(a.thr[i]);
   }
   switch (pat) {
     case 0: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 0), 4, 1, 2, 3, 0>(a, s);

@@ -20,7 +20,9 @@ namespace {
 template <typename T>
 __device__ __forceinline__ void flag_cell(const DiskArgs<T>& a, long long off, T lastval, T val) {
   const T diff = lastval - val;                            // raster dtype
-  const bool hit = (double)diff > a.thr;                   // float64 comparison (NumPy 2)
+  bool hit;                                                // float64 comparison (NumPy 2); fp32: smrf_float_below
+  if constexpr (sizeof(T) == 4) hit = diff > a.thr_lo;
+  else hit = (double)diff > a.thr;
   if (a.dense) {
     a.mask[off] = hit ? 1 : 0;
     if (a.when != nullptr) a.when[off] = hit ? (uint8_t)a.widx : (uint8_t)0;
@@ -189,7 +191,7 @@ int dilate_flag_api(const T* eroded, const T* last, T* opened, uint8_t* mask, ui
                     int out_rows, int radius, int nan_aware, int impl, void* stream, int dense = 0) {
   if (!last || !mask) return smrf_fail(SMRF_E_ARG, "null last/mask pointer");
   DiskArgs<T> a{};
-  a.in = eroded; a.out = opened; a.last = last; a.mask = mask; a.when = when; a.thr = thr; a.widx = widx;
+  a.in = eroded; a.out = opened; a.last = last; a.mask = mask; a.when = when; a.thr = thr; a.thr_lo = smrf_float_below(thr); a.widx = widx;
   a.img_rows = img_rows; a.cols = cols; a.ld = ld;
   a.in_row0 = in_row0; a.in_rows = in_rows; a.out_row0 = out_row0; a.out_rows = out_rows;
   a.radius = radius; a.nan_aware = nan_aware; a.nt = nt_rule<T>(img_rows, cols); a.dense = dense;
@@ -222,7 +224,7 @@ int open_flag_api(const T* last, T* opened, uint8_t* mask, uint8_t* when, double
   if (!smrf_fused_radius((int)sizeof(T), radius))
     return smrf_fail(SMRF_E_UNSUPPORTED, "no fused opening kernel for radius %d at this dtype", radius);
   DiskArgs<T> a{};
-  a.in = last; a.out = opened; a.mask = mask; a.when = when; a.thr = thr; a.widx = widx;
+  a.in = last; a.out = opened; a.mask = mask; a.when = when; a.thr = thr; a.thr_lo = smrf_float_below(thr); a.widx = widx;
   a.img_rows = img_rows; a.cols = cols; a.ld = ld;
   a.in_row0 = in_row0; a.in_rows = in_rows; a.out_row0 = out_row0; a.out_rows = out_rows;
   a.radius = 2 * radius;                               // the band check: `last` must reach 2r rows beyond the outputs

@@ -149,7 +149,9 @@ void fused_open_kernel(const DiskArgs<T> a) {
       else a.out[off] = outvD[i];
       if constexpr (MODE != 0) {
         const T diff = lastv[i] - outvD[i];                  // raster dtype
-        const bool hit = (double)diff > a.thr;               // float64 comparison (NumPy 2)
+        bool hit;                                            // float64 comparison (NumPy 2); fp32: smrf_float_below
+        if constexpr (sizeof(T) == 4) hit = diff > a.thr_lo;
+        else hit = (double)diff > a.thr;
         if constexpr (MODE == 2) {                           // first window of a call: every byte, the planes were not cleared
           a.mask[off] = hit ? 1 : 0;
           if (a.when != nullptr) a.when[off] = hit ? (uint8_t)a.widx : (uint8_t)0;

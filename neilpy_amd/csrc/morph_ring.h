@@ -431,7 +431,9 @@ __device__ __forceinline__ void smrf_store_out(T* p, T v, int nt) {
 template <typename T>
 __device__ __forceinline__ void smrf_flag_cell(const DiskArgs<T>& a, long long off, T lastval, T val) {
   const T diff = lastval - val;                            // raster dtype
-  const bool hit = (double)diff > a.thr;                   // float64 comparison (NumPy 2)
+  bool hit;                                                // float64 comparison (NumPy 2); fp32: smrf_float_below
+  if constexpr (sizeof(T) == 4) hit = diff > a.thr_lo;
+  else hit = (double)diff > a.thr;
   if (a.dense) {
     a.mask[off] = hit ? 1 : 0;
     if (a.when != nullptr) a.when[off] = hit ? (uint8_t)a.widx : (uint8_t)0;
@@ -1196,7 +1198,10 @@ void ring_kernel(const DiskArgs<T> a) {
       else a.out[off] = outv[i];
       if constexpr (FLAG) {
         const T diff = lastv[i] - outv[i];                   // raster dtype
-        if ((double)diff > a.thr) {                          // float64 comparison (NumPy 2)
+        bool hit;                                            // float64 comparison (NumPy 2); fp32: smrf_float_below
+        if constexpr (sizeof(T) == 4) hit = diff > a.thr_lo;
+        else hit = (double)diff > a.thr;
+        if (hit) {
           if constexpr (BUF) {
             const unsigned sm = (unsigned)(ro0 - bo + i) * (unsigned)a.ld;
             smrf_buf_store_u8(rs_mask, (unsigned)x, sm, (uint8_t)1);

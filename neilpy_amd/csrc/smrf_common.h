@@ -42,6 +42,16 @@ __host__ __device__ constexpr int smrf_isqrt(int v) {
   return r;
 }
 
+// largest float <= t.  The flag step compares the raster dtype's difference with the float64 threshold in float64
+// (neilpy.py:1671 under NumPy 2).  For a float `diff`: diff > t implies diff > thr_lo (thr_lo <= t); and diff > thr_lo
+// implies diff >= the next float above thr_lo, which lies above t by the choice of thr_lo.  So `diff > thr_lo` is the same
+// predicate, in one fp32 instruction instead of a conversion and a float64 compare (NaN: false either way).
+inline float smrf_float_below(double t) {
+  float f = (float)t;
+  if ((double)f > t) f = __builtin_nextafterf(f, -__builtin_inff());
+  return f;
+}
+
 // arguments of one disk erosion / dilation pass over a row band (see smrf_hip.h)
 template <typename T>
 struct DiskArgs {
@@ -51,6 +61,7 @@ struct DiskArgs {
   uint8_t* mask;      // flag step only
   uint8_t* when;      // flag step only, may be NULL
   double thr;
+  float thr_lo;       // largest float <= thr: for fp32 rasters `diff > thr_lo` decides exactly as `(double)diff > thr`
   int widx;
   int img_rows, cols;
   long long ld;

@@ -527,3 +527,34 @@ def test_integration_md_stub_runs(nz, orc):
     m2, w2 = orc.progressive_filter(Z, win, 1, .15, return_when_dropped=True)
     assert m.dtype == bool and np.array_equal(m, m2) and np.array_equal(w, w2)
     assert np.array_equal(ns["progressive_filter"](Z.astype(np.float64), win), m2)
+
+
+@pytest.mark.parametrize("route", ["default", "chain0", "fused0", "direct"])
+def test_flag_threshold_float_boundaries(nz, orc, monkeypatch, route):
+    """The flag step compares the raster dtype's difference with the float64 threshold in float64 (neilpy.py:1671 under
+    NumPy 2).  The fp32 kernels compare against the largest float <= threshold instead (smrf_float_below): spikes whose
+    height is the float just below / at / just above thresholds that are and are not float32 numbers must be flagged
+    exactly as the oracle flags them, on every route a window can take."""
+    for name in ("SMRF_FUSED", "SMRF_CHAIN"):
+        monkeypatch.delenv(name, raising=False)
+    if route == "chain0":
+        monkeypatch.setenv("SMRF_CHAIN", "0")
+    if route == "fused0":
+        monkeypatch.setenv("SMRF_FUSED", "0")
+    impl = 2 if route == "direct" else 0
+    for slope in (0.3, 0.75, 0.1, 1e-3, 7.0):              # 0.75 and 7.0 are float32 numbers, the others are not
+        for window in (1, 2, 4, 9, 11):
+            thr = slope * (window * 1)
+            f = np.float32(thr)
+            hs = [np.nextafter(np.nextafter(f, np.float32(-np.inf)), np.float32(-np.inf)), np.nextafter(f, np.float32(-np.inf)), f,
+                  np.nextafter(f, np.float32(np.inf)), np.nextafter(np.nextafter(f, np.float32(np.inf)), np.float32(np.inf))]
+            Z = np.zeros((96, 300), dtype=np.float32)
+            for k, h in enumerate(hs):
+                Z[20 + 12 * k, 40 + 50 * k] = h                # isolated spikes: the opening removes them, diff = h exactly
+            win = np.array([window])
+            got = nz.progressive_filter(Z, win, 1, slope, impl=impl)
+            want = orc.progressive_filter(Z, win, 1, slope)
+            assert np.array_equal(got, want), (route, slope, window)
+            assert int(want.sum()) == sum(1 for h in hs if float(h) > thr), (slope, window)
+            Zd = Z.astype(np.float64)
+            assert np.array_equal(nz.progressive_filter(Zd, win, 1, slope, impl=impl), orc.progressive_filter(Zd, win, 1, slope))
