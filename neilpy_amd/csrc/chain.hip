@@ -6,17 +6,20 @@
 namespace {
 
 struct Pattern { int n; int r[4]; long long min_cells; };
-// The chains that exist, longest first per starting radius (NP row pairs per batch - SMRF_CHAIN_NP - and the occupancy the
-// kernel is built for are per pattern, below); a single window is a chain of one: the same table-free stages, which for
-// R = 8..10 beat the table-building fused kernel (and the two ring passes of R = 9).  min_cells: the smallest raster the
-// pattern is taken for (a chain's segments start sum(2R) rows early; on a 4096^2 raster 6, 7 and 9, 10 lose to one launch
-// per window).  Measured against one launch per window on the 16384^2 benchmark (gpurun_out/r03u/rounds3.log):
-// 1, 2, 3: 0.79 against 1.96 ms; 4, 5: 0.84 against 1.42; 6, 7: 1.28 against 1.52; 8: 0.65 against 0.84; 9: 0.72 against
-// 1.07; 10: 0.79 against 0.99; 11..14 lose (1.05 against 0.86 at 11), a chain 8, 9 (172 registers) 3.1 against 2.0.
+// The launches that exist, in the order they are tried (NP row pairs per batch - SMRF_CHAIN_NP - and the occupancy a kernel
+// is built for are per pattern, below).  A single window is a chain of one: the same table-free stages, which up to
+// R = 10 beat the table-building fused kernel of morph_fused.h (and the two ring passes of R = 9): at R <= 6 they run at the
+// device's copy rate (0.55 ms for the 10 B/cell of a 16384^2 fp32 window).  min_cells: the smallest raster a pattern is
+// taken for (a chain's segments start sum(2R) rows early and its strips lose sum(2R) columns per side).
+// Measured on 16384^2 fp32 against round 2's one fused launch (two ring passes at R = 9) per window, ms
+// (profiles/r03_chain_windows.md): 1, 2, 3: 0.79 against 1.96; 4, 5: 0.84 against 1.42 (on 4096^2 two single launches
+// win: 0.103 against 0.114); 6: 0.55 against 0.76; 7: 0.67 against 0.79; 8: 0.65 against 0.84; 9: 0.72 against 1.07;
+// 10: 0.79 against 0.99; 11..14 lose (1.05 against 0.86 at 11); a chain 6, 7 takes 1.31 (two singles 1.22), a chain 8, 9
+// (172 registers, two workgroups per CU) 3.1 against 2.0: neither exists.
 constexpr long long kLarge = 48ll << 20;
-constexpr Pattern kPatterns[] = {{3, {1, 2, 3, 0}, 0}, {2, {1, 2, 0, 0}, 0}, {2, {2, 3, 0, 0}, 0}, {2, {4, 5, 0, 0}, 0},
-                                 {2, {6, 7, 0, 0}, kLarge}, {1, {8, 0, 0, 0}, 0}, {1, {9, 0, 0, 0}, kLarge},
-                                 {1, {10, 0, 0, 0}, kLarge}};
+constexpr Pattern kPatterns[] = {{3, {1, 2, 3, 0}, 0}, {2, {1, 2, 0, 0}, 0}, {2, {2, 3, 0, 0}, 0}, {2, {4, 5, 0, 0}, kLarge},
+                                 {1, {4, 0, 0, 0}, 0}, {1, {5, 0, 0, 0}, 0}, {1, {6, 0, 0, 0}, 0}, {1, {7, 0, 0, 0}, 0},
+                                 {1, {8, 0, 0, 0}, 0}, {1, {9, 0, 0, 0}, kLarge}, {1, {10, 0, 0, 0}, kLarge}};
 constexpr int kNPatterns = (int)(sizeof(kPatterns) / sizeof(kPatterns[0]));
 
 template <typename T>
@@ -30,10 +33,13 @@ int launch(int pat, const ChainArgs<T>& a_in, hipStream_t s) {
     case 1: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 1), 4, 1, 2, 0, 0>(a, s);
     case 2: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 2), 4, 2, 3, 0, 0>(a, s);
     case 3: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 3), 4, 4, 5, 0, 0>(a, s);
-    case 4: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 4), 3, 6, 7, 0, 0>(a, s);
-    case 5: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 5), 4, 8, 0, 0, 0>(a, s);
-    case 6: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 6), 4, 9, 0, 0, 0>(a, s);
-    case 7: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 7), 4, 10, 0, 0, 0>(a, s);
+    case 4: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 4), 4, 4, 0, 0, 0>(a, s);
+    case 5: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 5), 4, 5, 0, 0, 0>(a, s);
+    case 6: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 6), 4, 6, 0, 0, 0>(a, s);
+    case 7: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 7), 4, 7, 0, 0, 0>(a, s);
+    case 8: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 8), 4, 8, 0, 0, 0>(a, s);
+    case 9: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 9), 4, 9, 0, 0, 0>(a, s);
+    case 10: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 10), 4, 10, 0, 0, 0>(a, s);
     default: return smrf_fail(SMRF_E_ARG, "unknown chain pattern %d", pat);
   }
 }

@@ -54,7 +54,9 @@ constexpr bool fused_lastq(int r) {   // gpurun_out/r03k/lq.log: fp32 R = 2..7 -
 template <typename T, int R, int TW, int NP>
 constexpr int fused_min_blocks() {
   const int by_lds = (int)(160 * 1024 / (2 * RingCfg<T, R, TW, NP>::LDS_BYTES));
-  return by_lds < 1 ? 1 : (by_lds > 4 ? 4 : by_lds);
+  const int by_regs = R >= 19 ? 2 : R >= 15 ? 3 : 4;       // two rings of 2R registers: 128 per lane no longer hold them from R = 15
+  const int cap = by_lds < by_regs ? by_lds : by_regs;
+  return cap < 1 ? 1 : cap;
 }
 
 template <typename T, int R, int TW, int NP>
