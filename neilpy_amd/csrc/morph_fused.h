@@ -46,7 +46,7 @@ constexpr int fused_np(int r) {
 #define SMRF_FUSED_LASTQ(T, R) fused_lastq<T>(R)
 #endif
 template <typename T>
-constexpr bool fused_lastq(int r) {   // gpurun_out/r03k/lq.log: fp32 R = 2..7 -9...-17 %, R >= 8 lose a workgroup per CU to the queue's registers
+constexpr bool fused_lastq(int r) {   // profiles/r03_logs/lastq_ab_f32.log: fp32 R = 2..7 -9...-17 %, R >= 8 lose a workgroup per CU to the queue's registers
   return sizeof(T) == 4 ? (r >= 2 && r <= 7) : (r == 1 || r == 2 || r == 4 || r == 5);
 }
 

@@ -113,3 +113,35 @@ def test_every_radius_vs_oracle(nz, orc, dtype):
         assert e.dtype == dtype and np.array_equal(e, orc.erosion(Z, fp)), (r, "erosion")
         d = nz.dilation(Z, radius=r, impl=1)
         assert np.array_equal(d, orc.dilation(Z, fp)), (r, "dilation")
+
+
+def test_window_routes(nz, gpu_device, monkeypatch):
+    """how progressive_filter runs each window (smrf_progressive_filter_timed_*'s route report): chained small windows,
+    table-free single launches, fused openings, two ring passes - by radius and raster size; every route the same bits"""
+    import torch
+    from neilpy_amd import api, _lib
+    Z = torch.from_numpy(nz.synth_dem(512, seed=3)).to(gpu_device)
+    win = np.arange(1, 17)
+    thr = .15 * (win * 1)
+    C = _lib.ROUTE_CHAIN
+
+    def run():
+        t = {}
+        m, _ = api._progressive_filter_device(Z, win, thr, False, nan_aware=0, timing=t)
+        assert len(t["window_ms"]) == 16 and float(np.sum(t["window_ms"])) > 0
+        return m, [int(v) for v in t["route"]]
+
+    for name in ("SMRF_FUSED", "SMRF_CHAIN"):
+        monkeypatch.delenv(name, raising=False)
+    m0, r0 = run()                                          # a small raster: chains 1-3, singles 4..8, fused none above 8
+    assert r0 == [C, C + 1, C + 2, C, C, C, C, C] + [_lib.ROUTE_TWO_PASS] * 8
+    monkeypatch.setenv("SMRF_FUSED", "2")                   # every launch kind that exists, whatever the size
+    m2, r2 = run()
+    assert r2 == [C, C + 1, C + 2, C, C + 1, C, C, C, C, C] + [_lib.ROUTE_FUSED] * 4 + [_lib.ROUTE_TWO_PASS] * 2
+    monkeypatch.setenv("SMRF_CHAIN", "0")
+    m3, r3 = run()
+    assert r3 == [_lib.ROUTE_FUSED] * 8 + [_lib.ROUTE_TWO_PASS] + [_lib.ROUTE_FUSED] * 5 + [_lib.ROUTE_TWO_PASS] * 2
+    monkeypatch.setenv("SMRF_FUSED", "0")
+    m4, r4 = run()
+    assert r4 == [_lib.ROUTE_TWO_PASS] * 16
+    assert torch.equal(m0, m2) and torch.equal(m0, m3) and torch.equal(m0, m4)

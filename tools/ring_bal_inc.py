@@ -4,11 +4,13 @@
 Input: logs of ``tools/ring_probe.py --libs <a build with -DSMRF_RING_BAL=0>`` run with the library built with
 ``-DSMRF_RING_BAL_ALL=1`` as the current one - erosion and ``--flag`` runs, fp32 and fp64, any split of the radii:
 
-    python tools/ring_bal_inc.py --f32 gpurun_out/s2/bal_all_erode.log gpurun_out/s2/bal_all_flag.log ... \\
-                                 --f64 gpurun_out/s2/bal_f64all_erode.log gpurun_out/s2/bal_f64all_flag.log
+    python tools/ring_bal_inc.py --f32 <dir>/bal_all_erode.log <dir>/bal_all_flag.log ... \\
+                                 --f64 <dir>/bal_f64all_erode.log <dir>/bal_f64all_flag.log
 
 A radius is switched on when erosion + dilation/flag together are at least 0.7 % faster with the balanced build
 (run-to-run noise of the interleaved medians is about 1 %); radii from 59 up are left off (no consistent sign).
+The logs the committed table was written from are kept in profiles/tuning/r02_ring_table_inputs.tar.gz
+(bal_all_*.log / bal_more_*.log / bal_f64all_*.log; unpack into <dir>).
 """
 import argparse
 import os

@@ -5,10 +5,12 @@ neilpy_amd/csrc/ring_inc.inc.
 Input: logs of ``tools/ring_probe.py --libs <build with "-DSMRF_RING_INC(T,R)=1">`` run with a library built with
 ``"-DSMRF_RING_INC(T,R)=0"`` (or the tables all zero) as the current one - erosion and ``--flag`` runs per dtype:
 
-    python tools/ring_inc_inc.py --f32 gpurun_out/s2/inc_all_erode.log gpurun_out/s2/inc_all_flag.log \\
-                                 --f64 gpurun_out/s2/inc_f64all_erode.log gpurun_out/s2/inc_f64all_flag.log
+    python tools/ring_inc_inc.py --f32 <dir>/inc_all_erode.log <dir>/inc_all_flag.log \\
+                                 --f64 <dir>/inc_f64all_erode.log <dir>/inc_f64all_flag.log
 
 A radius is switched on when erosion + dilation/flag together are at least 0.7 % faster with it.
+The logs the committed table was written from are kept in profiles/tuning/r02_ring_table_inputs.tar.gz
+(inc_all_*.log / inc_f64all_*.log; unpack into <dir>).
 """
 import argparse
 import os

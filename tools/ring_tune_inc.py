@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """Turn the tables measured by tools/ring_tune.py into neilpy_amd/csrc/ring_tune.inc.
 
-    python tools/ring_tune_inc.py gpurun_out/ring_tune_f32.json gpurun_out/ring_tune_f64.json
+    python tools/ring_tune_inc.py <dir>/ring_tune_f32.json <dir>/ring_tune_f64.json
 
 Per radius the simplest build within 1% of the fastest wins: the default (n2d0) first, then the
 builds at the estimated occupancy, then the rest.
+The logs the committed table was written from are kept in profiles/tuning/r02_ring_table_inputs.tar.gz
+(ring_tune*_f32.json / ring_tune*_f64.json; unpack into <dir>).
 """
 import json
 import os
