@@ -334,7 +334,10 @@ struct RingCfg {
   // per batch, so that BOTH halves consume the window widths in the ascending order the lookups produce them and
   // only the last few widths stay live (about 2K - 2G registers less than the shifting second half, which walks the
   // widths downwards and so keeps all K of both rows until the end of the pair).  See ring_consume_inplace.
-  static constexpr bool INPLACE = INC && SMRF_RING_INPLACE(T, R);
+  // Where ring_inpl.inc marks a radius DUAL both forms exist - the in-place instance is the one with the table's row
+  // pairs per batch, any other NP is the shifting ring - and ring_launch takes the in-place one for long segments only.
+  static constexpr bool INPLACE = INC && SMRF_RING_INPLACE(T, R) &&
+                                  (!ring_tuned_inplace_dual<T>(R) || NP == SMRF_RING_INPLACE_NP(T, R));
   static constexpr int BASE_PB = SMRF_RING_BASE_PB(T, R) > 0 ? SMRF_RING_BASE_PB(T, R) : INPLACE ? 1 : 8;   // row pairs per round trip of the base-level build (in-place kernels are built for registers)
   static constexpr int NEED_BASE = INPLACE ? E * (2 * R + 2 * (G + 2) + 3 + 20 + 4 * G) + 16 + SMRF_RING_INPLACE_SLACK
                                            : E * (2 * R + 2 * S::K + 20 + 4 * G) + 16;   // measured VGPR demand at D = 2
@@ -1314,10 +1317,9 @@ void ring_kernel(const DiskArgs<T> a) {
   }
 }
 
-template <typename T, int R, bool DIL>
-int ring_launch(const DiskArgs<T>& a_in, hipStream_t stream) {
+template <typename T, int R, bool DIL, int NP>
+int ring_launch_np(const DiskArgs<T>& a_in, hipStream_t stream, bool probe_only, int* seg_if_launched) {
   constexpr int TW = SMRF_RING_TW_OF(T, R);
-  constexpr int NP = SMRF_RING_NP(T, R);
   using C = RingCfg<T, R, TW, NP>;
   auto kern = ring_kernel<T, R, DIL, TW, NP>;
   // workgroups one CU really holds (registers + LDS), per device: the attribute below is per device too
@@ -1336,8 +1338,9 @@ int ring_launch(const DiskArgs<T>& a_in, hipStream_t stream) {
     resident = std::max(1, nb);
     __atomic_store_n(&resident_of[dev], resident, __ATOMIC_RELEASE);
     if (smrf_env_int("SMRF_RING_DEBUG", 0))
-      fprintf(stderr, "smrf ring: R=%d %s%s NP=%d G=%d LDS=%zu built for %d waves/SIMD, %d workgroups/CU resident\n", R,
-              sizeof(T) == 4 ? "f32" : "f64", DIL ? " dilate" : " erode", NP, C::G, C::LDS_BYTES, C::OCC, resident);
+      fprintf(stderr, "smrf ring: R=%d %s%s NP=%d G=%d%s LDS=%zu built for %d waves/SIMD, %d workgroups/CU resident\n", R,
+              sizeof(T) == 4 ? "f32" : "f64", DIL ? " dilate" : " erode", NP, C::G, C::INPLACE ? " in-place" : "", C::LDS_BYTES,
+              C::OCC, resident);
   }
   DiskArgs<T> a = a_in;
   const int strips = (a.cols + TW - 1) / TW;
@@ -1362,10 +1365,33 @@ int ring_launch(const DiskArgs<T>& a_in, hipStream_t stream) {
     if (max_rows < C::ROWS) return smrf_fail(SMRF_E_UNSUPPORTED, "raster rows of %lld bytes are too long for this build", rowb);
     if (a.seg > max_rows) a.seg = (int)(max_rows / C::ROWS) * C::ROWS;
   }
+  if (seg_if_launched) *seg_if_launched = a.seg;
+  if (probe_only) return SMRF_OK;
   dim3 grid(strips, (a.out_rows + a.seg - 1) / a.seg);
   hipLaunchKernelGGL(kern, grid, dim3(TW), C::LDS_BYTES, stream, a);
   SMRF_LAUNCH_CHECK();
   return SMRF_OK;
+}
+
+template <typename T, int R, bool DIL>
+int ring_launch(const DiskArgs<T>& a_in, hipStream_t stream) {
+  constexpr int TW = SMRF_RING_TW_OF(T, R);
+  constexpr int NP = SMRF_RING_NP(T, R);                 // the shifting ring's row pairs per batch where a radius is dual
+  if constexpr (ring_tuned_inplace_dual<T>(R) && SMRF_RING_INPLACE(T, R)) {
+    // Both forms exist (ring_inpl.inc): the in-place instance runs a third workgroup per CU (3 waves per SIMD), worth
+    // 2-6 % when its segments are long and a loss when they are not (a third more segments, each with 2R warm-up
+    // rows: +5...11 % on a 4096^2 raster or a 2048-row band).  Taken when the segments it would march are >= 16 R rows.
+    constexpr int NPI = SMRF_RING_INPLACE_NP(T, R);
+    static_assert(NPI != NP, "a dual radius needs two different instances");
+    static_assert(RingCfg<T, R, TW, NPI>::INPLACE && !RingCfg<T, R, TW, NP>::INPLACE, "dual instances mixed up");
+    const int mode = smrf_env_int("SMRF_RING_DUAL", -1);    // tests / A-B runs: 0 = shifting ring, 1 = in place, -1 = by rule
+    int seg = 0;
+    if (mode != 0 && a_in.seg <= 0) {
+      if (int rc = ring_launch_np<T, R, DIL, NPI>(a_in, stream, true, &seg)) return rc;
+    }
+    if (mode == 1 || (mode < 0 && seg >= 16 * R)) return ring_launch_np<T, R, DIL, NPI>(a_in, stream, false, nullptr);
+  }
+  return ring_launch_np<T, R, DIL, NP>(a_in, stream, false, nullptr);
 }
 
 }  // namespace smrf

@@ -100,6 +100,22 @@ def test_w50_big_reference_golden(nz, gpu_device):
     assert sha(last.cpu().numpy()) == str(g["opened_last_sha1"])
 
 
+def test_dual_ring_instances_vs_oracle(nz, orc, monkeypatch):
+    """the radii with two ring instances (csrc/ring_inpl.inc: shifting ring for short segments, in-place 3-wave ring for
+    long ones): both forced in turn on a small raster, against the oracle"""
+    rng = np.random.default_rng(65)
+    shape = (130, 520)
+    Z = (rng.normal(0, 1, shape).cumsum(0).cumsum(1) * 0.05 + 200 + (rng.random(shape) < 0.05) * rng.uniform(1, 25, shape)).astype(np.float32)
+    for r in (39, 40, 43, 44, 46, 48):
+        fp = orc.disk(r)
+        we, wd = orc.erosion(Z, fp), orc.dilation(Z, fp)
+        for mode in ("0", "1"):
+            monkeypatch.setenv("SMRF_RING_DUAL", mode)
+            assert np.array_equal(nz.erosion(Z, radius=r, impl=1), we), (r, mode, "erosion")
+            assert np.array_equal(nz.dilation(Z, radius=r, impl=1), wd), (r, mode, "dilation")
+    monkeypatch.delenv("SMRF_RING_DUAL")
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_every_radius_vs_oracle(nz, orc, dtype):
     """ring kernels, every instantiated radius, erosion and dilation, 3 strips wide (about 70 s of oracle per dtype)"""
