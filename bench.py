@@ -130,7 +130,7 @@ def window_classes(Z, windows, thresholds, cells, elem, peak):
     api._progressive_filter_device(Z, windows, thresholds, False, nan_aware=0, timing=timing)   # warm (first-call setup)
     api._progressive_filter_device(Z, windows, thresholds, False, nan_aware=0, timing=timing)
     ms, route = timing["window_ms"], timing["route"]
-    # chains: route = ROUTE_CHAIN + position; the time of a chain is recorded on its last window, members before it 0
+    # chains: route = ROUTE_CHAIN + position; the time of a chain is recorded on its first window, the other members read ~0
     classes = {}
     i = 0
     while i < len(ms):

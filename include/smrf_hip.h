@@ -153,7 +153,8 @@ SMRF_API int smrf_progressive_filter_f64(const double* d_Z, int rows, int cols, 
 #define SMRF_ROUTE_FUSED 1      /* one fused opening + flag launch: 2s + 2 B/cell */
 #define SMRF_ROUTE_DIRECT 2     /* footprint-gather kernels, two passes (radius > SMRF_RING_MAX_RADIUS or impl = direct) */
 #define SMRF_ROUTE_COPY 3       /* radius 0 */
-#define SMRF_ROUTE_CHAIN 4      /* member of a chain of small windows opened in one launch (route = 4 + position in it) */
+#define SMRF_ROUTE_CHAIN 4      /* table-free launch of morph_chain.h: route = 4 + position in a chain of windows opened in one launch (its
+                                 * time is reported on position 0, the others read ~0); a single window is a chain of one */
 SMRF_API int smrf_progressive_filter_timed_f32(const float* d_Z, int rows, int cols, const int32_t* h_windows,
                                 const double* h_thresholds, int n_windows, uint8_t* d_mask,
                                 uint8_t* d_when_dropped, void* d_workspace, size_t workspace_bytes, int nan_aware,

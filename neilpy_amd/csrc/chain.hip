@@ -22,6 +22,10 @@ constexpr Pattern kPatterns[] = {{3, {1, 2, 3, 0}, 0}, {2, {1, 2, 0, 0}, 0}, {2,
                                  {1, {8, 0, 0, 0}, 0}, {1, {9, 0, 0, 0}, kLarge}, {1, {10, 0, 0, 0}, kLarge}};
 constexpr int kNPatterns = (int)(sizeof(kPatterns) / sizeof(kPatterns[0]));
 
+#ifndef SMRF_CHAIN_OCC
+#define SMRF_CHAIN_OCC 4       // waves per SIMD the chain kernels are built for (tuning builds override)
+#endif
+
 template <typename T>
 int launch(int pat, const ChainArgs<T>& a_in, hipStream_t s) {
   ChainArgs<T> a = a_in;
@@ -29,17 +33,17 @@ int launch(int pat, const ChainArgs<T>& a_in, hipStream_t s) {
     a.thr_lo[i] = smrf_float_below(a.thr[i]);
   }
   switch (pat) {
-    case 0: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 0), 4, 1, 2, 3, 0>(a, s);
-    case 1: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 1), 4, 1, 2, 0, 0>(a, s);
-    case 2: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 2), 4, 2, 3, 0, 0>(a, s);
-    case 3: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 3), 4, 4, 5, 0, 0>(a, s);
-    case 4: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 4), 4, 4, 0, 0, 0>(a, s);
-    case 5: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 5), 4, 5, 0, 0, 0>(a, s);
-    case 6: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 6), 4, 6, 0, 0, 0>(a, s);
-    case 7: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 7), 4, 7, 0, 0, 0>(a, s);
-    case 8: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 8), 4, 8, 0, 0, 0>(a, s);
-    case 9: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 9), 4, 9, 0, 0, 0>(a, s);
-    case 10: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 10), 4, 10, 0, 0, 0>(a, s);
+    case 0: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 0), SMRF_CHAIN_OCC, 1, 2, 3, 0>(a, s);
+    case 1: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 1), SMRF_CHAIN_OCC, 1, 2, 0, 0>(a, s);
+    case 2: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 2), SMRF_CHAIN_OCC, 2, 3, 0, 0>(a, s);
+    case 3: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 3), SMRF_CHAIN_OCC, 4, 5, 0, 0>(a, s);
+    case 4: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 4), SMRF_CHAIN_OCC, 4, 0, 0, 0>(a, s);
+    case 5: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 5), SMRF_CHAIN_OCC, 5, 0, 0, 0>(a, s);
+    case 6: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 6), SMRF_CHAIN_OCC, 6, 0, 0, 0>(a, s);
+    case 7: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 7), SMRF_CHAIN_OCC, 7, 0, 0, 0>(a, s);
+    case 8: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 8), SMRF_CHAIN_OCC, 8, 0, 0, 0>(a, s);
+    case 9: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 9), SMRF_CHAIN_OCC, 9, 0, 0, 0>(a, s);
+    case 10: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 10), SMRF_CHAIN_OCC, 10, 0, 0, 0>(a, s);
     default: return smrf_fail(SMRF_E_ARG, "unknown chain pattern %d", pat);
   }
 }

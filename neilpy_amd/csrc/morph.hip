@@ -317,7 +317,7 @@ int progressive_filter_api(const T* Z, int rows, int cols, const int32_t* window
       else crc = smrf_chain_f64(pat, c, stream);
       if (crc) return crc;
       if (nwin > 1) last = opened;
-      for (int k = 0; k < len; ++k)                        // the chain's time is recorded on its last window
+      for (int k = 0; k < len; ++k)                        // the chain's time lands on its first window, the others read ~0
         if (int rc = window_done(i + k, SMRF_ROUTE_CHAIN + k)) return rc;
       i += len;
       continue;

@@ -400,12 +400,18 @@ using smrf_rsrc_t = __amdgpu_buffer_rsrc_t;
 __device__ __forceinline__ smrf_rsrc_t smrf_make_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, -1, 0x00020000);
 }
+template <bool NT = false>
 __device__ __forceinline__ float smrf_buf_load(smrf_rsrc_t r, unsigned voff, unsigned soff, float) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, NT ? 2 : 0));
 }
+template <bool NT = false>
 __device__ __forceinline__ double smrf_buf_load(smrf_rsrc_t r, unsigned voff, unsigned soff, double) {
-  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, NT ? 2 : 0));
 }
+// `last` of the flag step in the ring dilation: read once per launch, never again - a streaming load (SMRF_NT_LAST)
+#ifndef SMRF_NT_LAST
+#define SMRF_NT_LAST 0
+#endif
 template <bool NT>
 __device__ __forceinline__ void smrf_buf_store(smrf_rsrc_t r, unsigned voff, unsigned soff, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, NT ? 2 : 0);
@@ -1245,11 +1251,12 @@ void ring_kernel(const DiskArgs<T> a) {
       if constexpr (BUF) {
         const unsigned s0 = (unsigned)(y0 - bl) * rowb;
 #pragma unroll
-        for (int i = 0; i < ROWS; ++i) lastv[i] = smrf_buf_load(rs_last, xcb, s0 + (unsigned)i * rowb, T());
+        for (int i = 0; i < ROWS; ++i) lastv[i] = smrf_buf_load<SMRF_NT_LAST != 0>(rs_last, xcb, s0 + (unsigned)i * rowb, T());
       } else {
       const T* l0 = a.last + (long long)y0 * a.ld + xc;
 #pragma unroll
-      for (int i = 0; i < ROWS; ++i) lastv[i] = l0[(long long)i * a.ld];
+      for (int i = 0; i < ROWS; ++i)
+        lastv[i] = SMRF_NT_LAST ? __builtin_nontemporal_load(&l0[(long long)i * a.ld]) : l0[(long long)i * a.ld];
       }
     } else {
 #pragma unroll
