@@ -33,19 +33,20 @@ int launch(int pat, const ChainArgs<T>& a_in, hipStream_t s) {
     a.thr_lo[i] = smrf_float_below(a.thr[i]);
   }
   switch (pat) {
-    case 0: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 0), SMRF_CHAIN_OCC, 1, 2, 3, 0>(a, s);
+    case 0: if constexpr (sizeof(T) == 4) return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 0), SMRF_CHAIN_OCC, 1, 2, 3, 0>(a, s); else break;   // fp32 only: the fp64 form spills
     case 1: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 1), SMRF_CHAIN_OCC, 1, 2, 0, 0>(a, s);
     case 2: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 2), SMRF_CHAIN_OCC, 2, 3, 0, 0>(a, s);
-    case 3: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 3), SMRF_CHAIN_OCC, 4, 5, 0, 0>(a, s);
-    case 4: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 4), SMRF_CHAIN_OCC, 4, 0, 0, 0>(a, s);
-    case 5: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 5), SMRF_CHAIN_OCC, 5, 0, 0, 0>(a, s);
-    case 6: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 6), SMRF_CHAIN_OCC, 6, 0, 0, 0>(a, s);
-    case 7: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 7), SMRF_CHAIN_OCC, 7, 0, 0, 0>(a, s);
-    case 8: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 8), SMRF_CHAIN_OCC, 8, 0, 0, 0>(a, s);
-    case 9: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 9), SMRF_CHAIN_OCC, 9, 0, 0, 0>(a, s);
-    case 10: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 10), SMRF_CHAIN_OCC, 10, 0, 0, 0>(a, s);
-    default: return smrf_fail(SMRF_E_ARG, "unknown chain pattern %d", pat);
+    case 3: if constexpr (sizeof(T) == 4) return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 3), SMRF_CHAIN_OCC, 4, 5, 0, 0>(a, s); else break;   // fp32 only: the fp64 form spills
+    case 4: if constexpr (sizeof(T) == 4) return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 4), SMRF_CHAIN_OCC, 4, 0, 0, 0>(a, s); else break;   // fp32 only: the fp64 form spills
+    case 5: if constexpr (sizeof(T) == 4) return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 5), SMRF_CHAIN_OCC, 5, 0, 0, 0>(a, s); else break;   // fp32 only: the fp64 form spills
+    case 6: if constexpr (sizeof(T) == 4) return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 6), SMRF_CHAIN_OCC, 6, 0, 0, 0>(a, s); else break;   // fp32 only: the fp64 form spills
+    case 7: if constexpr (sizeof(T) == 4) return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 7), SMRF_CHAIN_OCC, 7, 0, 0, 0>(a, s); else break;   // fp32 only: the fp64 form spills
+    case 8: if constexpr (sizeof(T) == 4) return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 8), SMRF_CHAIN_OCC, 8, 0, 0, 0>(a, s); else break;   // fp32 only: the fp64 form spills
+    case 9: if constexpr (sizeof(T) == 4) return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 9), SMRF_CHAIN_OCC, 9, 0, 0, 0>(a, s); else break;   // fp32 only: the fp64 form spills
+    case 10: if constexpr (sizeof(T) == 4) return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 10), SMRF_CHAIN_OCC, 10, 0, 0, 0>(a, s); else break;   // fp32 only: the fp64 form spills
+    default: break;
   }
+  return smrf_fail(SMRF_E_ARG, "no chain kernel for pattern %d at this dtype", pat);
 }
 
 }  // namespace

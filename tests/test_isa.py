@@ -44,3 +44,22 @@ def test_ring_unit_has_no_inflight_use_and_no_fused_lds_ops(tmp_path):
     assert text.count("ds_read_b64") > 1000                # radii 2, 10, ..., 58: the scan has something to look at
     assert check_isa.lds_hazards(text) == []
     assert "ds_read2" not in text and "ds_write2" not in text
+
+
+def test_chain_unit_has_no_inflight_use_no_scratch_loops(tmp_path):
+    """the chained / table-free kernels (csrc/morph_chain.h) read their neighbours' cells with the same asm reads and
+    counted waits: no use of a register in flight, no fused LDS ops, and no scratch beyond a few loop-invariant registers"""
+    import re
+    from neilpy_amd.build import CSRC, FLAGS, hipcc
+    out = str(tmp_path / "chain.s")
+    cmd = [hipcc()] + [f for f in FLAGS if f != "-fPIC"] + ["--offload-device-only", "-S", os.path.join(CSRC, "chain.hip"), "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = open(out).read()
+    assert text.count("ds_read_b64") > 300
+    assert check_isa.lds_hazards(text) == []
+    assert "ds_read2" not in text and "ds_write2" not in text
+    kernels = re.findall(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S)
+    assert len(kernels) == 13                               # 11 fp32 patterns + the two fp64 chains
+    for name, body in kernels:
+        assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1)) <= 16, name
