@@ -130,6 +130,25 @@ SMRF_API int smrf_pf_open_flag_f64(const double* d_last, double* d_opened, uint8
                           double threshold, int window_index, int img_rows, int cols, int64_t ld, int in_row0,
                           int in_rows, int out_row0, int out_rows, int radius, void* stream);
 
+/* Several CONSECUTIVE progressive_filter windows with small disks in ONE launch (csrc/morph_chain.h): opens `last` with
+ * disk(h_radii[0]), flags, opens the result with disk(h_radii[1]), flags, ...; only the LAST opened surface is written
+ * (d_opened), every window's flags go to d_mask / d_when_dropped (window i writes h_window_index[i]) exactly as a sequence of
+ * smrf_pf_open_flag_* calls would.  Replaces n iterations of the loop of neilpy/neilpy.py:1667-1676.  Row-band form: the band
+ * of `last` must reach sum(2 * radius) rows (reflected at the raster's true borders) beyond the output rows; flags are
+ * written for the output rows only.  No NaN rule.  smrf_pf_chain_length: how many of the windows at the head of h_radii one
+ * launch takes on a raster of raster_cells cells (0: none; e.g. 3 for 1, 2, 3, ...; 1 = a table-free single launch);
+ * smrf_pf_chain_flag_* returns SMRF_E_UNSUPPORTED unless n_windows is a length this function reports for those radii
+ * at some raster size. */
+SMRF_API int smrf_pf_chain_length(int elem_size, const int32_t* h_radii, int n, int64_t raster_cells);
+SMRF_API int smrf_pf_chain_flag_f32(const float* d_last, float* d_opened, uint8_t* d_mask, uint8_t* d_when_dropped,
+                           const int32_t* h_radii, const double* h_thresholds, const int32_t* h_window_index,
+                           int n_windows, int img_rows, int cols, int64_t ld, int in_row0, int in_rows, int out_row0,
+                           int out_rows, void* stream);
+SMRF_API int smrf_pf_chain_flag_f64(const double* d_last, double* d_opened, uint8_t* d_mask, uint8_t* d_when_dropped,
+                           const int32_t* h_radii, const double* h_thresholds, const int32_t* h_window_index,
+                           int n_windows, int img_rows, int cols, int64_t ld, int in_row0, int in_rows, int out_row0,
+                           int out_rows, void* stream);
+
 /* Whole progressive_filter on one device.  d_Z is read only.  h_windows / h_thresholds are HOST
  * arrays of n_windows entries; thresholds are slope_threshold*(windows*cellsize) evaluated by
  * the caller in float64 (neilpy.py:1661).  d_mask (rows*cols bytes, 0/1) and d_when_dropped

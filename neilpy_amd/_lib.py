@@ -37,6 +37,9 @@ SIGNATURES = {
     "smrf_fused_open_supported": (_i, [_i, _i]),
     "smrf_pf_open_flag_f32": (_i, [_p, _p, _p, _p, _d, _i, _i, _i, _i64, _i, _i, _i, _i, _i, _p]),
     "smrf_pf_open_flag_f64": (_i, [_p, _p, _p, _p, _d, _i, _i, _i, _i64, _i, _i, _i, _i, _i, _p]),
+    "smrf_pf_chain_length": (_i, [_i, _p, _i, _i64]),
+    "smrf_pf_chain_flag_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i64, _i, _i, _i, _i, _p]),
+    "smrf_pf_chain_flag_f64": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i64, _i, _i, _i, _i, _p]),
     "smrf_progressive_filter_workspace_bytes": (_sz, [_i, _i, _i]),
     "smrf_progressive_filter_f32": (_i, [_p, _i, _i, _p, _p, _i, _p, _p, _p, _sz, _i, _i, _p]),
     "smrf_progressive_filter_f64": (_i, [_p, _i, _i, _p, _p, _i, _p, _p, _p, _sz, _i, _i, _p]),

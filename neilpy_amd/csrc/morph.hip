@@ -238,6 +238,35 @@ int open_flag_api(const T* last, T* opened, uint8_t* mask, uint8_t* when, double
   return RingFn<T>::call(a, SMRF_RING_FUSED_OPEN, (hipStream_t)stream);
 }
 
+// several consecutive small windows on a row band in ONE launch (morph_chain.h), the row-band form of what
+// progressive_filter_api does on a whole raster
+template <typename T>
+int chain_flag_api(const T* last, T* opened, uint8_t* mask, uint8_t* when, const int32_t* radii, const double* thr,
+                   const int32_t* widx, int n, int img_rows, int cols, int64_t ld, int in_row0, int in_rows, int out_row0,
+                   int out_rows, void* stream) {
+  if (!last || !opened || !mask || !radii || !thr || !widx) return smrf_fail(SMRF_E_ARG, "null pointer");
+  if (n < 1 || n > 4) return smrf_fail(SMRF_E_ARG, "a chain has 1..4 windows (got %d)", n);
+  const int pat = smrf_chain_match((int)sizeof(T), radii, n, 1ll << 62);
+  if (pat < 0 || smrf_chain_length(pat) != n)
+    return smrf_fail(SMRF_E_UNSUPPORTED, "no chained launch for these %d radii at this dtype (smrf_pf_chain_length tells)", n);
+  DiskArgs<T> b{};                                         // the band check: `last` must reach sum(2r) rows beyond the outputs
+  b.in = last; b.out = opened; b.img_rows = img_rows; b.cols = cols; b.ld = ld;
+  b.in_row0 = in_row0; b.in_rows = in_rows; b.out_row0 = out_row0; b.out_rows = out_rows;
+  b.radius = smrf_chain_halo(pat);
+  if (int rc = check_band(b)) return rc;
+  if (b.radius >= img_rows) return smrf_fail(SMRF_E_UNSUPPORTED, "raster of %d rows is shorter than the chain's %d halo rows", img_rows, b.radius);
+  ChainArgs<T> c{};
+  c.in = last; c.out = opened; c.mask = mask; c.when = when;
+  for (int k = 0; k < n; ++k) { c.thr[k] = thr[k]; c.widx[k] = widx[k]; }
+  c.img_rows = img_rows; c.cols = cols; c.ld = ld;
+  c.in_row0 = in_row0; c.in_rows = in_rows; c.out_row0 = out_row0; c.out_rows = out_rows;
+  c.seg = smrf_env_int("SMRF_RING_SEG", 0);
+  c.nt = nt_rule<T>(img_rows, cols);
+  c.dense0 = 0;
+  if constexpr (sizeof(T) == 4) return smrf_chain_f32(pat, c, (hipStream_t)stream);
+  else return smrf_chain_f64(pat, c, (hipStream_t)stream);
+}
+
 template <typename T>
 int progressive_filter_api(const T* Z, int rows, int cols, const int32_t* windows, const double* thr, int nwin,
                            uint8_t* mask, uint8_t* when, void* ws, size_t ws_bytes, int nan_aware, int impl,
@@ -389,6 +418,25 @@ int smrf_pf_open_flag_f64(const double* d_last, double* d_opened, uint8_t* d_mas
   if (!d_last || !d_opened) return smrf_fail(SMRF_E_ARG, "null raster pointer");
   return open_flag_api<double>(d_last, d_opened, d_mask, d_when_dropped, threshold, window_index, img_rows, cols, ld, in_row0,
                                in_rows, out_row0, out_rows, radius, stream);
+}
+int smrf_pf_chain_length(int elem_size, const int32_t* h_radii, int n, int64_t raster_cells) {
+  if (!h_radii || n < 1) return 0;
+  const int pat = smrf_chain_match(elem_size, h_radii, n, (long long)raster_cells);
+  return pat < 0 ? 0 : smrf_chain_length(pat);
+}
+int smrf_pf_chain_flag_f32(const float* d_last, float* d_opened, uint8_t* d_mask, uint8_t* d_when_dropped,
+                           const int32_t* h_radii, const double* h_thresholds, const int32_t* h_window_index, int n_windows,
+                           int img_rows, int cols, int64_t ld, int in_row0, int in_rows, int out_row0, int out_rows,
+                           void* stream) {
+  return chain_flag_api<float>(d_last, d_opened, d_mask, d_when_dropped, h_radii, h_thresholds, h_window_index, n_windows,
+                               img_rows, cols, ld, in_row0, in_rows, out_row0, out_rows, stream);
+}
+int smrf_pf_chain_flag_f64(const double* d_last, double* d_opened, uint8_t* d_mask, uint8_t* d_when_dropped,
+                           const int32_t* h_radii, const double* h_thresholds, const int32_t* h_window_index, int n_windows,
+                           int img_rows, int cols, int64_t ld, int in_row0, int in_rows, int out_row0, int out_rows,
+                           void* stream) {
+  return chain_flag_api<double>(d_last, d_opened, d_mask, d_when_dropped, h_radii, h_thresholds, h_window_index, n_windows,
+                                img_rows, cols, ld, in_row0, in_rows, out_row0, out_rows, stream);
 }
 size_t smrf_progressive_filter_workspace_bytes(int rows, int cols, int elem_size) {
   return (size_t)3 * (size_t)rows * (size_t)cols * (size_t)elem_size;

@@ -69,6 +69,30 @@ class HipBandOps:
         import torch
         return 1 <= radius <= 8 and bool(self.lib.smrf_fused_open_supported(4 if t.dtype == torch.float32 else 8, int(radius)))
 
+    def chain_len(self, t, radii, raster_cells):
+        """how many of the windows at the head of ``radii`` one chained / table-free launch takes on a raster of this size
+        (csrc/morph_chain.h; 0 = none)"""
+        import os
+        import torch
+        if os.environ.get("SMRF_CHAIN") == "0":              # as in smrf_progressive_filter_*: every small window its own launch
+            return 0
+        r = np.ascontiguousarray(np.asarray(radii[:4], dtype=np.int32))
+        return int(self.lib.smrf_pf_chain_length(4 if t.dtype == torch.float32 else 8, r.ctypes.data_as(C.c_void_p), int(r.size),
+                                                 int(raster_cells)))
+
+    def chain_flag(self, last, last_row0, opened, mask, when, radii, thr, widx, out_row0, out_rows, img_rows):
+        """the windows ``radii`` opened one after the other in ONE launch: ``opened`` = the last surface on global rows
+        [out_row0, out_row0 + out_rows), every window's flags on those rows; ``last`` reaches sum(2r) rows beyond them"""
+        fn = getattr(self.lib, "smrf_pf_chain_flag_" + self._sfx(last))
+        cols = last.shape[1]
+        r = np.ascontiguousarray(np.asarray(radii, dtype=np.int32))
+        t = np.ascontiguousarray(np.asarray(thr, dtype=np.float64))
+        w = np.ascontiguousarray(np.asarray(widx, dtype=np.int32))
+        _lib.check(fn(C.c_void_p(last.data_ptr()), C.c_void_p(opened.data_ptr()), C.c_void_p(mask.data_ptr()),
+                      C.c_void_p(when.data_ptr()) if when is not None else C.c_void_p(0), r.ctypes.data_as(C.c_void_p),
+                      t.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), int(r.size), img_rows, cols, cols, last_row0,
+                      last.shape[0], out_row0, out_rows, self._stream()))
+
     def open_flag(self, last, last_row0, opened, mask, when, thr, widx, out_row0, out_rows, img_rows, radius):
         """opened = opening(last, disk(r)) on global rows [out_row0, out_row0 + out_rows) + the flag step, one launch;
         ``last`` holds global rows from ``last_row0`` and reaches 2r rows beyond the outputs"""
@@ -258,9 +282,29 @@ def progressive_filter_sharded(Z_band, img_rows, windows, thresholds, *, rank=No
                 posted = None
             else:
                 exchange(ext[cur], M)
-        for i in grp:
+        gpos = 0
+        while gpos < len(grp):
+            i = grp[gpos]
+            gpos += 1
             r = windows[i]
             last = ext[cur]
+            # runs of small windows inside a group as ONE launch (HipBandOps.chain_flag): the margin they eat is the sum of
+            # theirs; not with NaNs (no NaN rule there) and not where the group's last window is split edge-first (overlap)
+            if (world_size > 1 and not nan_aware and not overlap and hasattr(ops, "chain_len")):
+                k = ops.chain_len(last, [windows[j] for j in grp[gpos - 1:]], img_rows * cols)
+                if k >= 1:
+                    members = grp[gpos - 1:gpos - 1 + k]
+                    lo, hi = max(0, b0 - M), min(img_rows, b1 + M)
+                    M -= sum(2 * windows[j] for j in members)
+                    o0, o1 = max(0, b0 - M), min(img_rows, b1 + M)
+                    nxt = ext[1 - cur]
+                    ops.chain_flag(last[lo - e0:hi - e0], lo, nxt[o0 - e0:o1 - e0], mask[o0 - e0:o1 - e0],
+                                   when[o0 - e0:o1 - e0] if when is not None else None, [windows[j] for j in members],
+                                   [float(thresholds[j]) for j in members], members, o0, o1 - o0, img_rows)
+                    gpos += k - 1
+                    if len(windows) > 1:
+                        cur = 1 - cur
+                    continue
             if world_size == 1:
                 lo, hi, q0, q1, o0, o1 = 0, img_rows, 0, img_rows, 0, img_rows
             else:

@@ -69,10 +69,15 @@ def test_w50_mid_reference_golden(nz, monkeypatch, fused, chain):
     assert np.array_equal(last, g["opened_last"])             # the 50th opened surface, bit for bit
 
 
-@pytest.mark.parametrize("which,world", [("mid", 4), ("big", 8)])
-def test_w50_row_band_driver(nz, gpu_device, which, world):
-    """the sharded driver's bands (4 x 192 rows, 8 x 256 rows) with all 50 windows against the reference's mask"""
+@pytest.mark.parametrize("which,world,chain", [("mid", 4, None), ("big", 8, None), ("mid", 4, "0")])
+def test_w50_row_band_driver(nz, gpu_device, monkeypatch, which, world, chain):
+    """the sharded driver's bands (4 x 192 rows, 8 x 256 rows) with all 50 windows against the reference's mask; the small
+    windows of a group as chained / table-free launches (default) or one fused launch each (SMRF_CHAIN=0)"""
     import torch
+    if chain is None:
+        monkeypatch.delenv("SMRF_CHAIN", raising=False)
+    else:
+        monkeypatch.setenv("SMRF_CHAIN", chain)
     g, Z = w50(which, nz)
     Zd = torch.from_numpy(Z).to(gpu_device)
     mask, when, groups = run_bands(nz, Zd, g["windows"], world, return_when_dropped=True)
