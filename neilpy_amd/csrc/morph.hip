@@ -287,10 +287,30 @@ int progressive_filter_api(const T* Z, int rows, int cols, const int32_t* window
     SMRF_HIP_CHECK(hipMemsetAsync(mask, 0, plane, stream));
     if (when) SMRF_HIP_CHECK(hipMemsetAsync(when, 0, plane, stream));
   }
+  // nan_aware < 0: the library finds out itself.  When the call starts with a chained / table-free launch, that launch
+  // carries the scan (it loads every cell of the raster; ChainArgs::nan_flag): it runs as if there were no NaN, the
+  // flag is read back after it (the one synchronising readback a separate count would need as well), and in the rare
+  // case it is set the call starts over on the NaN-aware two-pass kernels.  Otherwise: one count pass first.
+  const int fuse_mode0 = smrf_env_int("SMRF_FUSED", 1);
+  const bool may_chain = nan_aware < 0 && nwin > 0 && fuse_mode0 != 0 && smrf_env_int("SMRF_CHAIN", 1) != 0 &&
+                         smrf_env_int("SMRF_NAN_RIDE", 1) != 0 &&   // 0: always a separate count pass (A/B runs)
+                         (impl == SMRF_IMPL_AUTO || impl == SMRF_IMPL_RING);
+  const int pat0 = may_chain ? smrf_chain_match((int)sizeof(T), windows, nwin, fuse_mode0 == 2 ? (1ll << 62) : (long long)plane) : -1;
+  unsigned* d_nan = nullptr;                               // the flag of a speculative first launch
+  struct FlagGuard {
+    unsigned*& p; hipStream_t st;
+    ~FlagGuard() { if (p) hipFreeAsync(p, st); }
+  } flag_guard{d_nan, stream};
   if (nan_aware < 0) {
-    int64_t c = 0;
-    if (int rc = count_nan_api<T>(Z, (int64_t)plane, &c, stream_)) return rc;
-    nan_aware = c > 0;
+    if (pat0 >= 0 && smrf_chain_halo(pat0) < rows) {
+      SMRF_HIP_CHECK(hipMallocAsync((void**)&d_nan, sizeof(unsigned), stream));
+      SMRF_HIP_CHECK(hipMemsetAsync(d_nan, 0, sizeof(unsigned), stream));
+      nan_aware = 0;
+    } else {
+      int64_t c = 0;
+      if (int rc = count_nan_api<T>(Z, (int64_t)plane, &c, stream_)) return rc;
+      nan_aware = c > 0;
+    }
   }
   // measurement form (smrf_progressive_filter_timed_*): an event on the stream at every window boundary
   struct Events {                                          // destroyed on every way out
@@ -323,13 +343,15 @@ int progressive_filter_api(const T* Z, int rows, int cols, const int32_t* window
   // SMRF_FUSED: 0 = never, 1 = default rule, 2 = every radius that has a fused kernel whatever the raster size (tests);
   // SMRF_CHAIN: 0 = no chains (every window its own launch).
   const int fuse_mode = smrf_env_int("SMRF_FUSED", 1);
-  const bool fuse_ok = !nan_aware && (impl == SMRF_IMPL_AUTO || impl == SMRF_IMPL_RING) && fuse_mode != 0;
-  const bool chain_ok = fuse_ok && smrf_env_int("SMRF_CHAIN", 1) != 0;
+  const bool fuse_ok0 = (impl == SMRF_IMPL_AUTO || impl == SMRF_IMPL_RING) && fuse_mode != 0;
+  const bool chain_ok0 = smrf_env_int("SMRF_CHAIN", 1) != 0;
   int flip = 0;                                          // which of the two opened planes the next launch writes
   for (int i = 0; i < nwin;) {
     const int r = windows[i];
     T* opened = O[flip];
     flip ^= 1;
+    const bool fuse_ok = !nan_aware && fuse_ok0;           // (nan_aware can change once: a speculative first launch that met a NaN)
+    const bool chain_ok = fuse_ok && chain_ok0;
     const int pat = chain_ok ? smrf_chain_match((int)sizeof(T), windows + i, nwin - i, fuse_mode == 2 ? (1ll << 62) : (long long)plane) : -1;
     if (pat >= 0 && smrf_chain_halo(pat) < rows) {
       const int len = smrf_chain_length(pat);
@@ -341,10 +363,24 @@ int progressive_filter_api(const T* Z, int rows, int cols, const int32_t* window
       c.seg = smrf_env_int("SMRF_RING_SEG", 0);
       c.nt = nt_rule<T>(rows, cols);
       c.dense0 = i == 0;
+      c.nan_flag = i == 0 ? d_nan : nullptr;
       int crc;
       if constexpr (sizeof(T) == 4) crc = smrf_chain_f32(pat, c, stream);
       else crc = smrf_chain_f64(pat, c, stream);
       if (crc) return crc;
+      if (i == 0 && d_nan) {                               // the speculative first launch: did it meet a NaN?
+        unsigned h = 0;
+        SMRF_HIP_CHECK(hipMemcpyAsync(&h, d_nan, sizeof(h), hipMemcpyDeviceToHost, stream));
+        SMRF_HIP_CHECK(hipStreamSynchronize(stream));
+        SMRF_HIP_CHECK(hipFreeAsync(d_nan, stream));
+        d_nan = nullptr;
+        if (h) {                                           // start over with scipy's NaN rule (two-pass kernels only)
+          nan_aware = 1;
+          flip = 0;
+          last = Z;
+          continue;                                        // i is still 0
+        }
+      }
       if (nwin > 1) last = opened;
       for (int k = 0; k < len; ++k)                        // the chain's time lands on its first window, the others read ~0
         if (int rc = window_done(i + k, SMRF_ROUTE_CHAIN + k)) return rc;

@@ -45,6 +45,7 @@ struct ChainArgs {
   int seg;            // output rows per workgroup (0: the launcher decides)
   int nt;             // output cells as non-temporal stores
   int dense0;         // the first window writes EVERY mask / when byte (the call's first window: planes not cleared)
+  unsigned* nan_flag; // if not NULL: set to 1 when any input cell this launch loads is NaN (it loads every cell of the band)
 };
 
 // chain dispatch (chain.hip): the pattern a window list starts with (-1: none), its length and halo rows, the launch
@@ -279,11 +280,19 @@ void chain_kernel(const ChainArgs<T> a) {
     }
   };
 
+  // the call's NaN scan riding along (smrf_progressive_filter_* with nan_aware < 0): every input cell passes through some
+  // lane's prefetch, so one unordered compare per loaded value replaces a separate pass over the raster
+  const bool scan = a.nan_flag != nullptr;
+  bool seen_nan = false;
   prefetch();
   for (int yy0 = ystart; yy0 < ye + S; yy0 += ROWS) {
     T2 cur[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) cur[p] = pf[p];
+    if (scan) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) seen_nan = seen_nan || cur[p].x != cur[p].x || cur[p].y != cur[p].y;
+    }
     if (yy0 > ystart) epilogue(yy0 - ROWS);                // stores older than the loads issued next
     if (yy0 + ROWS < ye + S) prefetch();
     [&]<int... I>(std::integer_sequence<int, I...>) {
@@ -339,6 +348,7 @@ void chain_kernel(const ChainArgs<T> a) {
     const int nb = (ye + S - ystart + ROWS - 1) / ROWS;
     epilogue(ystart + (nb - 1) * ROWS);
   }
+  if (scan && seen_nan) atomicOr(a.nan_flag, 1u);
 }
 
 template <typename T, int NP, int OCC, int R0, int R1, int R2, int R3>

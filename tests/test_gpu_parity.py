@@ -558,3 +558,24 @@ def test_flag_threshold_float_boundaries(nz, orc, monkeypatch, route):
             assert int(want.sum()) == sum(1 for h in hs if float(h) > thr), (slope, window)
             Zd = Z.astype(np.float64)
             assert np.array_equal(nz.progressive_filter(Zd, win, 1, slope, impl=impl), orc.progressive_filter(Zd, win, 1, slope))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_nan_anywhere_is_found_by_the_first_launch(nz, orc, dtype):
+    """progressive_filter finds out about NaNs itself: when the call starts with a chained launch that launch carries
+    the scan (csrc/morph.hip), runs as if there were none and the call starts over on the NaN-aware kernels if it met
+    one.  A single NaN in any corner, on any edge or in the middle of a 3-strip raster must give the oracle's result."""
+    rng = np.random.default_rng(31)
+    shape = (300, 700)
+    base = rand_dem(rng, shape, dtype)
+    win = np.arange(1, 6)
+    spots = [(0, 0), (0, 699), (299, 0), (299, 699), (0, 350), (299, 351), (150, 0), (151, 699), (150, 256), (37, 511)]
+    for r, c in spots:
+        Z = base.copy()
+        Z[r, c] = np.nan
+        m, w = nz.progressive_filter(Z, win, 1, .15, return_when_dropped=True)
+        m2, w2 = orc.progressive_filter(Z, win, 1, .15, return_when_dropped=True)
+        assert np.array_equal(m, m2) and np.array_equal(w, w2), (r, c)
+    m, w = nz.progressive_filter(base, win, 1, .15, return_when_dropped=True)      # and without one
+    m2, w2 = orc.progressive_filter(base, win, 1, .15, return_when_dropped=True)
+    assert np.array_equal(m, m2) and np.array_equal(w, w2)
