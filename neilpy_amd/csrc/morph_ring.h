@@ -87,6 +87,11 @@
 #ifndef SMRF_RING_BAL
 #define SMRF_RING_BAL 1
 #endif
+// highest table level of the incremental widths (RingCfg::INC): 3 (eight cells per read), or 2 where no width step of the
+// disk is longer than 8 cells (two reads of level 2 per side cover it): one level less to build and to hold in LDS
+#ifndef SMRF_RING_JCAP
+#define SMRF_RING_JCAP(T, R) ring_tuned_jcap<T>(R)
+#endif
 // second half of the ring updated in place (RingCfg::INPLACE): per radius from ring_inpl.inc, or everywhere / nowhere in
 // tuning builds; SLACK: registers added to the kernel's demand estimate (tuning the occupancy step it is built for)
 #ifndef SMRF_RING_INPLACE
@@ -124,6 +129,16 @@ constexpr int ring_occ_drop(int occ, int steps) {
 #include "ring_inc.inc"
 #include "ring_inpl.inc"
 #include "ring_buf.inc"
+// Highest table level of the incremental widths per radius (RingCfg::INC, SMRF_RING_JCAP).  Level 3 (eight cells per
+// read) is only ever read for the FIRST width step of a disk (isqrt(2R - 1) cells: 5..11 for R = 15..64); with the cap at 2
+// that step takes two (three from R = 41) reads of level 2 per side and one or two more min / max, and level 3 is neither
+// built (4 of the 7 reads and 4 of the 8 instructions of the build per cell and row pair) nor held in LDS.  fp32, two-pass
+// windows, 16384^2 / 4096^2 (profiles/r03_logs/jcap2_all_radii.log): -1...-6 % at most radii from 15 to 58; the radii left
+// at 3 lose with it (29, 31, 46, 50; 59 and up spill); the fused kernels (R <= 14) and fp64 keep 3 (R = 14 fused: +24 %).
+template <typename T> constexpr int ring_tuned_jcap(int r) {
+  if (sizeof(T) != 4 || r < 15 || r > 58) return 3;
+  return (r == 29 || r == 31 || r == 46 || r == 50) ? 3 : 2;
+}
 
 // columns per workgroup per radius: 256 everywhere (512-column workgroups, one per CU, measured within +-1 % of 256 at
 // R >= 39 and 20-25 % slower below: gpurun_out/r02/probe_tw512.log)
@@ -273,7 +288,7 @@ struct RingCfg {
   static constexpr int inc_lev(int k) {                  // table level of the reads for width index k >= 1
     const int d = S::wk(k) - S::wk(k - 1);
     int j = 0;
-    while ((1 << j) < d && j < 3) ++j;
+    while ((1 << j) < d && j < SMRF_RING_JCAP(T, R)) ++j;
     return j;
   }
   static constexpr int inc_n(int k) {                    // reads per side
@@ -774,6 +789,7 @@ __device__ __forceinline__ void ring_consume(typename Vec2<T>::type* const L, co
     __builtin_amdgcn_s_setprio(SMRF_RING_LOOKUP_PRIO);
     T ra[K], rb[K];                                      // window results of row A / row B per width
     T2 ta[D][G], tb[D][G], tc[D][G], td[D][G];          // D lookup groups in flight (tc: third read of the widest widths; INC: tc, td second read per side)
+    T2 te[D][G], tf[D][G];                               // INC: third read per side (a first step of 9..11 cells at level 2)
     // INC reads level 0 as well: this batch's copy of it
     // (addressed from the row's first staged cell: ds_read offsets are unsigned)
     const unsigned q0 = q + (unsigned)par * (unsigned)(WP * sizeof(T2)) - (unsigned)(R * sizeof(T2));
@@ -785,14 +801,18 @@ __device__ __forceinline__ void ring_consume(typename Vec2<T>::type* const L, co
              constexpr int w = S::wk(k);
              constexpr int j = C::inc_lev(k);
              static_assert(C::stored(j), "step level not built");
-             static_assert(C::inc_n(k) <= 2, "width step longer than two table entries");
+             static_assert(C::inc_n(k) <= 3, "width step longer than three table entries");
              constexpr int base = j == 0 ? R : C::slot_of(j) * WP;
              const unsigned qq = j == 0 ? q0 : q;
              ta[GI % D][I] = lds_read2<(base - w) * (int)sizeof(T2)>(qq, T());
              tb[GI % D][I] = lds_read2<(base + w - (1 << j) + 1) * (int)sizeof(T2)>(qq, T());
-             if constexpr (C::inc_n(k) == 2) {
+             if constexpr (C::inc_n(k) >= 2) {
                tc[GI % D][I] = lds_read2<(base - w + (1 << j)) * (int)sizeof(T2)>(qq, T());
                td[GI % D][I] = lds_read2<(base + w - (2 << j) + 1) * (int)sizeof(T2)>(qq, T());
+             }
+             if constexpr (C::inc_n(k) == 3) {
+               te[GI % D][I] = lds_read2<(base - w + (2 << j)) * (int)sizeof(T2)>(qq, T());
+               tf[GI % D][I] = lds_read2<(base + w - (3 << j) + 1) * (int)sizeof(T2)>(qq, T());
              }
            } else if constexpr (k < K) {
              constexpr int w = S::wk(k);
@@ -814,9 +834,13 @@ __device__ __forceinline__ void ring_consume(typename Vec2<T>::type* const L, co
            if constexpr (k < K && C::INC) {
              T a = op3<DIL>(ra[k - 1], ta[GI % D][I].x, tb[GI % D][I].x);
              T b = op3<DIL>(rb[k - 1], ta[GI % D][I].y, tb[GI % D][I].y);
-             if constexpr (C::inc_n(k) == 2) {
+             if constexpr (C::inc_n(k) >= 2) {
                a = op3<DIL>(a, tc[GI % D][I].x, td[GI % D][I].x);
                b = op3<DIL>(b, tc[GI % D][I].y, td[GI % D][I].y);
+             }
+             if constexpr (C::inc_n(k) == 3) {
+               a = op3<DIL>(a, te[GI % D][I].x, tf[GI % D][I].x);
+               b = op3<DIL>(b, te[GI % D][I].y, tf[GI % D][I].y);
              }
              ra[k] = a;
              rb[k] = b;
@@ -901,7 +925,7 @@ __device__ __forceinline__ void ring_consume_inplace(typename Vec2<T>::type* con
     const unsigned q = lds_q + P * NLEV * WP * (unsigned)sizeof(T2);
     __builtin_amdgcn_s_setprio(SMRF_RING_LOOKUP_PRIO);
     T ra[K], rb[K];
-    T2 ta[D][G], tb[D][G], tc[D][G], td[D][G];
+    T2 ta[D][G], tb[D][G], tc[D][G], td[D][G], te[D][G], tf[D][G];
     const unsigned q0 = q + (unsigned)par * (unsigned)(WP * sizeof(T2)) - (unsigned)(R * sizeof(T2));
     auto issue = [&]<int GI>(std::integral_constant<int, GI>) {
       [&]<int... I>(std::integer_sequence<int, I...>) {
@@ -911,14 +935,18 @@ __device__ __forceinline__ void ring_consume_inplace(typename Vec2<T>::type* con
              constexpr int w = S::wk(k);
              constexpr int j = C::inc_lev(k);
              static_assert(C::stored(j), "step level not built");
-             static_assert(C::inc_n(k) <= 2, "width step longer than two table entries");
+             static_assert(C::inc_n(k) <= 3, "width step longer than three table entries");
              constexpr int base = j == 0 ? R : C::slot_of(j) * WP;
              const unsigned qq = j == 0 ? q0 : q;
              ta[GI % D][I] = lds_read2<(base - w) * (int)sizeof(T2)>(qq, T());
              tb[GI % D][I] = lds_read2<(base + w - (1 << j) + 1) * (int)sizeof(T2)>(qq, T());
-             if constexpr (C::inc_n(k) == 2) {
+             if constexpr (C::inc_n(k) >= 2) {
                tc[GI % D][I] = lds_read2<(base - w + (1 << j)) * (int)sizeof(T2)>(qq, T());
                td[GI % D][I] = lds_read2<(base + w - (2 << j) + 1) * (int)sizeof(T2)>(qq, T());
+             }
+             if constexpr (C::inc_n(k) == 3) {
+               te[GI % D][I] = lds_read2<(base - w + (2 << j)) * (int)sizeof(T2)>(qq, T());
+               tf[GI % D][I] = lds_read2<(base + w - (3 << j) + 1) * (int)sizeof(T2)>(qq, T());
              }
            }
          }()), ...);
@@ -931,9 +959,13 @@ __device__ __forceinline__ void ring_consume_inplace(typename Vec2<T>::type* con
            if constexpr (k < K) {
              T a = op3<DIL>(ra[k - 1], ta[GI % D][I].x, tb[GI % D][I].x);
              T b = op3<DIL>(rb[k - 1], ta[GI % D][I].y, tb[GI % D][I].y);
-             if constexpr (C::inc_n(k) == 2) {
+             if constexpr (C::inc_n(k) >= 2) {
                a = op3<DIL>(a, tc[GI % D][I].x, td[GI % D][I].x);
                b = op3<DIL>(b, tc[GI % D][I].y, td[GI % D][I].y);
+             }
+             if constexpr (C::inc_n(k) == 3) {
+               a = op3<DIL>(a, te[GI % D][I].x, tf[GI % D][I].x);
+               b = op3<DIL>(b, te[GI % D][I].y, tf[GI % D][I].y);
              }
              ra[k] = a;
              rb[k] = b;
