@@ -103,6 +103,21 @@
 #ifndef SMRF_RING_INPLACE_SLACK
 #define SMRF_RING_INPLACE_SLACK 0
 #endif
+// in-place instances from R = 39 up (the 3-wave ones whose register budget is the point; R = 15..17 and 36 measured
+// +-0 ... +2.6 percent with either and keep round 3's first form): smrf_rare, and the turn-back of the ring as asm moves
+// in-place instances: lookups per group / groups in flight (0: as the shifting ring, SMRF_RING_G / SMRF_RING_DEPTH)
+#ifndef SMRF_RING_INPLACE_G
+#define SMRF_RING_INPLACE_G(T, R) ring_tuned_inplace_g<T>(R)
+#endif
+#ifndef SMRF_RING_INPLACE_D
+#define SMRF_RING_INPLACE_D(T, R) 0
+#endif
+#ifndef SMRF_RING_RARE_OPAQUE
+#define SMRF_RING_RARE_OPAQUE(T, R) ((R) >= 39)
+#endif
+#ifndef SMRF_RING_TURN_ASM
+#define SMRF_RING_TURN_ASM(T, R) ((R) >= 39)
+#endif
 // in-place kernels: waves per SIMD they are built for and most row pairs per batch (per radius from ring_inpl.inc)
 #ifndef SMRF_RING_INPLACE_OCC
 #define SMRF_RING_INPLACE_OCC(T, R) ring_tuned_inplace_occ<T>(R)
@@ -341,9 +356,6 @@ struct RingCfg {
   }
   static constexpr int NLEV = slot_of(J) + 1;
   static constexpr size_t LDS_BYTES = ((size_t)NP * NLEV * WP + PAD) * 2 * sizeof(T);
-  static constexpr int G = SMRF_RING_G(E * (2 * R + 2 * S::K));   // window lookups per pipelined group
-  static constexpr int NG = (S::K - 1 + G - 1) / G;      // groups for k = 1..K-1
-  static constexpr int gsize(int g) { int n = S::K - 1 - g * G; return n < 0 ? 0 : (n > G ? G : n); }
   // INPLACE (round 3): the ring's second half (slots R-1 .. 2R-1, output rows below the input row) is updated IN PLACE,
   // the slot <-> register mapping rotating by two per row pair (compile-time inside a batch) and one register rotation
   // per batch, so that BOTH halves consume the window widths in the ascending order the lookups produce them and
@@ -353,10 +365,14 @@ struct RingCfg {
   // pairs per batch, any other NP is the shifting ring - and ring_launch takes the in-place one for long segments only.
   static constexpr bool INPLACE = INC && SMRF_RING_INPLACE(T, R) &&
                                   (!ring_tuned_inplace_dual<T>(R) || NP == SMRF_RING_INPLACE_NP(T, R));
+  static constexpr int G = INPLACE && SMRF_RING_INPLACE_G(T, R) > 0 ? SMRF_RING_INPLACE_G(T, R)
+                                                                     : SMRF_RING_G(E * (2 * R + 2 * S::K));   // window lookups per pipelined group
+  static constexpr int NG = (S::K - 1 + G - 1) / G;      // groups for k = 1..K-1
+  static constexpr int gsize(int g) { int n = S::K - 1 - g * G; return n < 0 ? 0 : (n > G ? G : n); }
   static constexpr int BASE_PB = SMRF_RING_BASE_PB(T, R) > 0 ? SMRF_RING_BASE_PB(T, R) : INPLACE ? 1 : 8;   // row pairs per round trip of the base-level build (in-place kernels are built for registers)
   static constexpr int NEED_BASE = INPLACE ? E * (2 * R + 2 * (G + 2) + 3 + 20 + 4 * G) + 16 + SMRF_RING_INPLACE_SLACK
                                            : E * (2 * R + 2 * S::K + 20 + 4 * G) + 16;   // measured VGPR demand at D = 2
-  static constexpr int D = SMRF_RING_DEPTH(NEED_BASE);   // lookup groups kept in flight
+  static constexpr int D = INPLACE && SMRF_RING_INPLACE_D(T, R) > 0 ? SMRF_RING_INPLACE_D(T, R) : SMRF_RING_DEPTH(NEED_BASE);   // lookup groups kept in flight
   static constexpr int greads(int g) {                   // LDS reads of lookup group g
     int n = 0;
     for (int k = 1 + g * G; k < 1 + (g + 1) * G && k < S::K; ++k) n += INC ? 2 * inc_n(k) : nreads(S::wk(k));
@@ -411,6 +427,23 @@ constexpr int ring_np() {
 #ifndef SMRF_RING_BUF
 #define SMRF_RING_BUF(T, R) ring_tuned_buf<T>(R)
 #endif
+// ... but not in the in-place instances of R = 47, 49 (3 waves per SIMD): there the descriptors' offsets cost the registers
+// the instance was built to save (20 / 36 B of scratch with, 0 / 12 B without)
+#ifndef SMRF_RING_INPLACE_NOBUF
+#define SMRF_RING_INPLACE_NOBUF(T, R) ((R) > 45)
+#endif
+template <typename T, int R, int TW, int NP>
+constexpr bool ring_buf_on() { return SMRF_RING_BUF(T, R) && !(RingCfg<T, R, TW, NP>::INPLACE && SMRF_RING_INPLACE_NOBUF(T, R)); }
+// a lane's column index made opaque on the rare paths (reflected / clamped rows, the NaN rule, segment ends) of the in-place
+// instances: without it hipcc hoists their loop-invariant 64-bit addresses (plane + column) out of the row loop and keeps a
+// VGPR pair per plane alive through the consume phase for code that runs on a few batches per segment - registers the
+// 3-wave instances do not have (R = 47, 50: 44 / 20 B of scratch without, none with).  The shifting instances keep the
+// hoisted form (R = 26..34 measured 1.5-3 percent slower with the opaque one, profiles/r03_logs/turn2_ab.log).
+template <bool ON>
+__device__ __forceinline__ int smrf_rare(int v) {
+  if constexpr (ON) asm volatile("" : "+v"(v));
+  return v;
+}
 using smrf_rsrc_t = __amdgpu_buffer_rsrc_t;
 __device__ __forceinline__ smrf_rsrc_t smrf_make_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, -1, 0x00020000);
@@ -1028,8 +1061,15 @@ __device__ __forceinline__ void ring_consume_inplace(typename Vec2<T>::type* con
       T t[M];
 #pragma unroll
       for (int i = 0; i < M; ++i) t[i] = acc[R - 1 + (i + ROT) % M];
+      // as asm moves: left to the compiler the copies are sunk to the next batch's tied updates and multiply there
+      // (R = 46: 102 v_mov per batch, 12 B of scratch; as asm 70 and none - M = 47 of them are the turn itself)
+      if constexpr (sizeof(T) == 4 && SMRF_RING_TURN_ASM(T, R)) {
 #pragma unroll
-      for (int i = 0; i < M; ++i) acc[R - 1 + i] = t[i];
+        for (int i = 0; i < M; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(acc[R - 1 + i]) : "v"(t[i]));
+      } else {
+#pragma unroll
+        for (int i = 0; i < M; ++i) acc[R - 1 + i] = t[i];
+      }
     }
   }
 }
@@ -1043,12 +1083,14 @@ __device__ __forceinline__ void ring_build_consume(typename Vec2<T>::type* const
   // the build phases end in barriers the whole workgroup waits at: let a wave in them win the issue arbitration
   // against the SIMD's other wave (which is usually consuming); measured -3...-5.5 % at every radius >= 8
   __builtin_amdgcn_s_setprio(SMRF_RING_BUILD_PRIO);
+#ifndef SMRF_RING_DBG_NOBUILD   // (timing experiment only, wrong results: what the table build costs)
   ring_base<T, R, DIL, TW, NP, NPB, OFF>(L, par, tid, has_last, v);
   phase_sync();
   if constexpr (RingCfg<T, R, TW, NP>::J > RingCfg<T, R, TW, NP>::JB) {
     ring_upper<T, R, DIL, TW, NP, NPB, OFF>(L, tid, has_last, v);
     phase_sync();
   }
+#endif
   __builtin_amdgcn_s_setprio(0);
   ring_consume<T, R, DIL, TW, NP>(L, par, tid, acc, outv);
 }
@@ -1101,6 +1143,9 @@ void ring_kernel(const DiskArgs<T> a) {
   // workgroup-wide when the table is shared by several waves; a single-wave workgroup owns its
   // table and only has to keep the compiler from moving LDS accesses across the phase boundary
   auto phase_sync = [&]() {
+#ifdef SMRF_RING_DBG_NOSYNC   // timing experiment only (wrong results): what the workgroup barriers cost
+    asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); return;
+#endif
     if constexpr (TW > 64) __syncthreads();
     else { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
   };
@@ -1125,7 +1170,8 @@ void ring_kernel(const DiskArgs<T> a) {
   RowFold rf(ystart, a.img_rows);                        // tracks the NEXT batch to prefetch
   // buffer addressing of the common cases (SMRF_RING_BUF): descriptors based at the first row of each plane this
   // workgroup touches there, byte offsets of the lane's columns; the host keeps a segment's span below 4 GiB
-  constexpr bool BUF = SMRF_RING_BUF(T, R);
+  constexpr bool BUF = ring_buf_on<T, R, TW, NP>();
+  constexpr bool RARE = C::INPLACE && SMRF_RING_RARE_OPAQUE(T, R);
   const int bi = max(0, ystart - a.in_row0);                       // first band row of `in` a fast-path batch can start at
   const int bl = max(0, ys - 2 * R - DELTA - a.out_row0);          // ... of `last` (first batch: outputs of rows ystart - R ...)
   const int bo = ys - a.out_row0;                                  // ... of `out`, `mask`, `when`
@@ -1197,7 +1243,7 @@ void ring_kernel(const DiskArgs<T> a) {
         const T* ra = a.in + (long long)la * a.ld;
         const T* rb = a.in + (long long)lb * a.ld;
 #pragma unroll
-        for (int i = 0; i < (BAL ? 1 : NPOS); ++i) { pf[p][i].x = ra[cpos[i]]; pf[p][i].y = rb[cpos[i]]; }
+        for (int i = 0; i < (BAL ? 1 : NPOS); ++i) { const int c = smrf_rare<RARE>(cpos[i]); pf[p][i].x = ra[c]; pf[p][i].y = rb[c]; }
       }
       if constexpr (BAL) {
 #pragma unroll
@@ -1208,8 +1254,9 @@ void ring_kernel(const DiskArgs<T> a) {
           int lb = rf.at(2 * pq + 1) - a.in_row0;
           la = la < 0 ? 0 : (la > last_in ? last_in : la);
           lb = lb < 0 ? 0 : (lb > last_in ? last_in : lb);
-          pfh[j].x = a.in[(long long)la * a.ld + hcol];
-          pfh[j].y = a.in[(long long)lb * a.ld + hcol];
+          const int hc = smrf_rare<RARE>(hcol);
+          pfh[j].x = a.in[(long long)la * a.ld + hc];
+          pfh[j].y = a.in[(long long)lb * a.ld + hc];
         }
       }
     }
@@ -1220,7 +1267,7 @@ void ring_kernel(const DiskArgs<T> a) {
     if (a.nan_aware) {
       // scipy: the first visited footprint element (offset (-R, 0)) decides NaN-ness
       const int ly = smrf_fold(yo - R, a.img_rows) - a.in_row0;
-      const T first = a.in[(long long)ly * a.ld + x];
+      const T first = a.in[(long long)ly * a.ld + smrf_rare<RARE>(x)];
       if (first != first) val = qnan<T>();
     }
     smrf_store_out(&a.out[off], val, a.nt);
@@ -1271,9 +1318,10 @@ void ring_kernel(const DiskArgs<T> a) {
         else emit_rows(std::false_type{}, std::false_type{}, off0, ro0);
       }
     } else {
+      const long long off0r = (long long)(yob - a.out_row0) * a.ld + smrf_rare<RARE>(x);
 #pragma unroll
       for (int i = 0; i < ROWS; ++i)
-        if (yob + i < ye) emit(yob + i, off0 + (long long)i * a.ld, outv[i], lastv[i]);
+        if (yob + i < ye) emit(yob + i, off0r + (long long)i * a.ld, outv[i], lastv[i]);
     }
   };
   auto load_last = [&](int yyb) {
@@ -1295,7 +1343,7 @@ void ring_kernel(const DiskArgs<T> a) {
       for (int i = 0; i < ROWS; ++i) {
         int yo = y0 + i;
         yo = yo < 0 ? 0 : (yo >= a.out_rows ? a.out_rows - 1 : yo);
-        lastv[i] = a.last[(long long)yo * a.ld + xc];
+        lastv[i] = a.last[(long long)yo * a.ld + smrf_rare<RARE>(xc)];
       }
     }
   };
@@ -1336,6 +1384,7 @@ void ring_kernel(const DiskArgs<T> a) {
       // ring_build_consume with the halo cells as wave-jobs: every wave builds its own 256 cells' worth of each row
       // pair plus its share of the halo, so the waves reach the phase barriers together
       __builtin_amdgcn_s_setprio(SMRF_RING_BUILD_PRIO);
+#ifndef SMRF_RING_DBG_NOBUILD
       ring_base<T, R, DIL, TW, NP, 1, 0>(L, par, tid, true, v);
       ring_base_halo<T, R, DIL, TW, NP>(L, par, hl, vh);
       phase_sync();
@@ -1344,6 +1393,7 @@ void ring_kernel(const DiskArgs<T> a) {
         ring_upper_halo<T, R, DIL, TW, NP>(L, hl, vh);
         phase_sync();
       }
+#endif
       __builtin_amdgcn_s_setprio(0);
       ring_consume<T, R, DIL, TW, NP>(L, par, tid, acc, outv);
     } else {
@@ -1396,7 +1446,7 @@ int ring_launch_np(const DiskArgs<T>& a_in, hipStream_t stream, bool probe_only,
     a.seg = seg;
   }
   a.seg = ((a.seg + C::ROWS - 1) / C::ROWS) * C::ROWS;
-  if constexpr (SMRF_RING_BUF(T, R)) {
+  if constexpr (ring_buf_on<T, R, TW, NP>()) {
     // buffer addressing: a workgroup's row offsets are 32-bit (and not range-checked by the hardware): keep the span of
     // a segment (its rows + warm-up + one batch) below 2 GiB
     const long long rowb = (long long)a.ld * (long long)sizeof(T);
