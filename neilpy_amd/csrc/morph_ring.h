@@ -113,10 +113,10 @@
 #define SMRF_RING_INPLACE_D(T, R) 0
 #endif
 #ifndef SMRF_RING_RARE_OPAQUE
-#define SMRF_RING_RARE_OPAQUE(T, R) ((R) >= 39)
+#define SMRF_RING_RARE_OPAQUE(T, R) ((R) >= 39 || ring_tuned_inplace_occ<T>(R) == 4)
 #endif
 #ifndef SMRF_RING_TURN_ASM
-#define SMRF_RING_TURN_ASM(T, R) ((R) >= 39)
+#define SMRF_RING_TURN_ASM(T, R) ((R) >= 39 || ring_tuned_inplace_occ<T>(R) == 4)
 #endif
 // in-place kernels: waves per SIMD they are built for and most row pairs per batch (per radius from ring_inpl.inc)
 #ifndef SMRF_RING_INPLACE_OCC

@@ -44,12 +44,14 @@ def w50(which, nz):
     return g, Z
 
 
-@pytest.mark.parametrize("fused,chain", [(None, None), ("0", None), ("2", None), ("2", "0"), (None, "0")])
-def test_w50_mid_reference_golden(nz, monkeypatch, fused, chain):
+@pytest.mark.parametrize("fused,chain,dual", [(None, None, None), ("0", None, None), ("2", None, None), ("2", "0", None),
+                                              (None, "0", None), (None, None, "1"), ("0", None, "1")])
+def test_w50_mid_reference_golden(nz, monkeypatch, fused, chain, dual):
     """default routing (chained small windows, fused, two-pass), two-pass everywhere (SMRF_FUSED=0), every chain / fused
     kernel that exists whatever the raster size (SMRF_FUSED=2), the same without chains (SMRF_CHAIN=0: every small window
-    through its own fused launch)"""
-    for name, val in (("SMRF_FUSED", fused), ("SMRF_CHAIN", chain)):
+    through its own fused launch); SMRF_RING_DUAL=1: the in-place ring instances the 16384^2 benchmark runs on its long
+    segments (csrc/ring_inpl.inc, 17 radii) forced on this raster - erosion and dilation + flag step of each"""
+    for name, val in (("SMRF_FUSED", fused), ("SMRF_CHAIN", chain), ("SMRF_RING_DUAL", dual)):
         if val is None:
             monkeypatch.delenv(name, raising=False)
         else:
@@ -106,12 +108,12 @@ def test_w50_big_reference_golden(nz, gpu_device):
 
 
 def test_dual_ring_instances_vs_oracle(nz, orc, monkeypatch):
-    """the radii with two ring instances (csrc/ring_inpl.inc: shifting ring for short segments, in-place 3-wave ring for
-    long ones): both forced in turn on a small raster, against the oracle"""
+    """the radii with two ring instances (csrc/ring_inpl.inc: shifting ring for short segments, in-place 3- or 4-wave ring
+    for long ones): both forced in turn on a small raster, against the oracle"""
     rng = np.random.default_rng(65)
     shape = (130, 520)
     Z = (rng.normal(0, 1, shape).cumsum(0).cumsum(1) * 0.05 + 200 + (rng.random(shape) < 0.05) * rng.uniform(1, 25, shape)).astype(np.float32)
-    for r in (39, 40, 41, 42, 43, 44, 45, 46, 48):
+    for r in (21, 22, 23, 30, 33, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50):
         fp = orc.disk(r)
         we, wd = orc.erosion(Z, fp), orc.dilation(Z, fp)
         for mode in ("0", "1"):
