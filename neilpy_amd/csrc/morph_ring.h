@@ -1191,6 +1191,15 @@ void ring_kernel(const DiskArgs<T> a) {
     xcb = (unsigned)xc * (unsigned)sizeof(T);
   }
   auto prefetch = [&]() {
+#ifdef SMRF_RING_DBG_NOLOAD   // timing experiment only (wrong results): the kernel without its loads from HBM
+    {
+      for (int p = 0; p < NP; ++p)
+        for (int i = 0; i < NPOS; ++i) { pf[p][i].x = (T)(tid + p); pf[p][i].y = (T)(tid - i); }
+      for (int j = 0; j < H::NJ; ++j) { pfh[j].x = (T)tid; pfh[j].y = (T)j; }
+      rf.advance(ROWS);
+      return;
+    }
+#endif
     const int l0 = rf.p - a.in_row0;
     if (rf.p + ROWS <= rf.n && l0 >= 0 && l0 + ROWS - 1 <= last_in) {
       // common case: ROWS consecutive rows inside the band, no reflection: one address, row strides
@@ -1307,6 +1316,13 @@ void ring_kernel(const DiskArgs<T> a) {
   auto epilogue = [&](int yyb) {
     const int yob = yyb - R;                               // first output row of the batch
     if (yob < ys || x >= a.cols) return;                   // (aligned: yob < ys means all rows are)
+#ifdef SMRF_RING_DBG_NOSTORE   // timing experiment only (wrong results): the kernel without its stores (kept alive by a test no value passes)
+    {
+      bool any = false;
+      for (int i = 0; i < ROWS; ++i) any |= (outv[i] == (T)-12345.678f) | (lastv[i] == (T)-12345.678f);
+      if (!any) return;
+    }
+#endif
     const long long off0 = (long long)(yob - a.out_row0) * a.ld + x;
     if (yob + ROWS <= ye && !a.nan_aware && !a.dense) {
       const int ro0 = yob - a.out_row0;
@@ -1326,6 +1342,9 @@ void ring_kernel(const DiskArgs<T> a) {
   };
   auto load_last = [&](int yyb) {
     if (!flag) return;
+#ifdef SMRF_RING_DBG_NOLOAD
+    { for (int i = 0; i < ROWS; ++i) lastv[i] = (T)-1e30f; return; }   // (no cell is flagged)
+#endif
     const int y0 = yyb - R - a.out_row0;
     if (y0 >= 0 && y0 + ROWS <= a.out_rows) {
       if constexpr (BUF) {
