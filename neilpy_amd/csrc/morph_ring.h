@@ -1486,9 +1486,9 @@ int ring_launch(const DiskArgs<T>& a_in, hipStream_t stream) {
   constexpr int TW = SMRF_RING_TW_OF(T, R);
   constexpr int NP = SMRF_RING_NP(T, R);                 // the shifting ring's row pairs per batch where a radius is dual
   if constexpr (ring_tuned_inplace_dual<T>(R) && SMRF_RING_INPLACE(T, R)) {
-    // Both forms exist (ring_inpl.inc): the in-place instance runs a third workgroup per CU (3 waves per SIMD), worth
-    // 2-6 % when its segments are long and a loss when they are not (a third more segments, each with 2R warm-up
-    // rows: +5...11 % on a 4096^2 raster or a 2048-row band).  Taken when the segments it would march are >= 16 R rows.
+    // Both forms exist (ring_inpl.inc): the in-place instance runs one more workgroup per CU (3 or 4 waves per SIMD), worth
+    // 3-7 % when its segments are long and a loss when they are not (more segments, each with 2R warm-up rows: +3...11 %
+    // on a 4096^2 raster or a 2048-row band).  Taken when the segments it would march are >= 16 R rows.
     constexpr int NPI = SMRF_RING_INPLACE_NP(T, R);
     static_assert(NPI != NP, "a dual radius needs two different instances");
     static_assert(RingCfg<T, R, TW, NPI>::INPLACE && !RingCfg<T, R, TW, NP>::INPLACE, "dual instances mixed up");
