@@ -1110,13 +1110,26 @@ void ring_kernel(const DiskArgs<T> a) {
   // segments): neighbouring strips share 2R halo columns, which then hit the same L2.  Placement
   // only, any mapping is correct (MI355X_MICROARCH: workgroup dispatch, XCD placement).
   int bx = blockIdx.x, by = blockIdx.y;
-#if SMRF_RING_XCD_REMAP
+#if SMRF_RING_XCD_REMAP == 2
+  {   // tuning build: an XCD owns a contiguous range of tiles in segment-major order (all strips of the same rows together)
+    const int total = gridDim.x * gridDim.y;
+    if ((total & 7) == 0) {
+      const int id = blockIdx.y * gridDim.x + blockIdx.x;
+      const int t = (id & 7) * (total >> 3) + (id >> 3);
+      bx = t % gridDim.x;
+      by = t / gridDim.x;
+    }
+  }
+#elif SMRF_RING_XCD_REMAP
   if ((gridDim.x & 7) == 0) {
     const int id = blockIdx.y * gridDim.x + blockIdx.x, per = gridDim.x >> 3;
     const int xcd = id & 7, slot = id >> 3;
     bx = xcd * per + slot % per;
     by = slot / per;
   }
+#endif
+#ifdef SMRF_RING_DBG_CLOCK   // timing experiment only: the shader clock this workgroup ran at, left in the output's first two cells
+  const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_q0 = __builtin_amdgcn_s_memrealtime();
 #endif
   const int x0 = bx * TW;
   const int x = x0 + tid;
@@ -1423,6 +1436,13 @@ void ring_kernel(const DiskArgs<T> a) {
     const int nb = (ye + R - ystart + ROWS - 1) / ROWS;
     epilogue(ystart + (nb - 1) * ROWS);
   }
+#ifdef SMRF_RING_DBG_CLOCK
+  if (bx == gridDim.x / 2 && by == gridDim.y / 2 && tid == 0) {
+    __threadfence();
+    a.out[0] = (T)(float)(__builtin_amdgcn_s_memtime() - dbg_t0);
+    a.out[1] = (T)(float)(__builtin_amdgcn_s_memrealtime() - dbg_q0);
+  }
+#endif
 }
 
 template <typename T, int R, bool DIL, int NP>
