@@ -44,6 +44,16 @@ def test_ring_unit_has_no_inflight_use_and_no_fused_lds_ops(tmp_path):
     assert text.count("ds_read_b64") > 1000                # radii 2, 10, ..., 58: the scan has something to look at
     assert check_isa.lds_hazards(text) == []
     assert "ds_read2" not in text and "ds_write2" not in text
+    # the in-place instances of this unit (csrc/ring_inpl.inc: R = 42 with 3 row pairs per batch, R = 50 with 2, both built for
+    # 3 waves per SIMD = 168 VGPRs) keep the whole ring in registers: no scratch
+    import re
+    kernels = dict(re.findall(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S))
+    for r, np_ in ((42, 3), (50, 2)):
+        for dil in (0, 1):
+            name = "_ZN4smrf11ring_kernelIfLi%dELb%dELi256ELi%dEEEv8DiskArgsIT_E" % (r, dil, np_)
+            assert name in kernels, name
+            assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", kernels[name]).group(1)) == 0, name
+            assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", kernels[name]).group(1)) <= 168, name
 
 
 def test_chain_unit_has_no_inflight_use_no_scratch_loops(tmp_path):
