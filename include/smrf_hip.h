@@ -76,6 +76,11 @@ SMRF_API int smrf_abi_version(void);
 SMRF_API const char* smrf_last_error(void);
 /* number of visible HIP devices (0 when there is none); never fails */
 SMRF_API int smrf_device_count(void);
+/* (diagnostic) The SMRF_* environment switches (SMRF_FUSED, SMRF_CHAIN, SMRF_NT, SMRF_RING_DUAL, SMRF_RING_SEG, ... - developer
+ * A/B runs and the parity tests that force every launch variant on small rasters) are read ONCE, when the library first needs
+ * them; no launch path calls getenv.  A process that changes them afterwards calls this to have them read again.  Not
+ * thread-safe against concurrent launches. */
+SMRF_API void smrf_switches_reload(void);
 
 /* ------------------------------------------------------------------------------------------
  * Grey erosion / dilation by skimage's disk(radius) with scipy's mode='reflect' borders.

@@ -30,6 +30,7 @@ SIGNATURES = {
     "smrf_abi_version": (_i, []),
     "smrf_last_error": (C.c_char_p, []),
     "smrf_device_count": (_i, []),
+    "smrf_switches_reload": (None, []),
     "smrf_disk_filter_f32": (_i, [_p, _p, _i, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "smrf_disk_filter_f64": (_i, [_p, _p, _i, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "smrf_pf_dilate_flag_f32": (_i, [_p, _p, _p, _p, _p, _d, _i, _i, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _p]),
@@ -105,6 +106,12 @@ def load():
         raise SmrfHipError("libsmrf_hip ABI version %d, expected 1" % lib.smrf_abi_version())
     _lib = lib
     return lib
+
+
+def reload_switches():
+    """have the library read its SMRF_* environment switches again (it reads them once, at load): tests and A/B tools
+    that change them inside a process"""
+    load().smrf_switches_reload()
 
 
 def check(rc):

@@ -7,6 +7,31 @@ namespace {
 thread_local char g_err[512] = "";
 }
 
+namespace {
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+SmrfSwitches read_switches() {
+  SmrfSwitches s;
+  s.fused = env_int("SMRF_FUSED", 1);
+  s.chain = env_int("SMRF_CHAIN", 1);
+  s.nan_ride = env_int("SMRF_NAN_RIDE", 1);
+  s.nt = env_int("SMRF_NT", -1);
+  s.ring_seg = env_int("SMRF_RING_SEG", 0);
+  s.ring_dual = env_int("SMRF_RING_DUAL", -1);
+  s.ring_rounds = env_int("SMRF_RING_ROUNDS", 1);
+  s.fused_rounds = env_int("SMRF_FUSED_ROUNDS", 1);
+  s.chain_rounds = env_int("SMRF_CHAIN_ROUNDS", 3);
+  s.ring_debug = env_int("SMRF_RING_DEBUG", 0);
+  s.ring_ends = env_int("SMRF_RING_ENDS", -1);
+  return s;
+}
+SmrfSwitches g_sw = read_switches();                       // at library load; smrf_switches_reload() reads again
+}  // namespace
+
+const SmrfSwitches& smrf_sw() { return g_sw; }
+
 int smrf_fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -20,6 +45,8 @@ extern "C" {
 int smrf_abi_version(void) { return SMRF_ABI_VERSION; }
 
 const char* smrf_last_error(void) { return g_err; }
+
+void smrf_switches_reload(void) { g_sw = read_switches(); }
 
 int smrf_device_count(void) {
   int n = 0;

@@ -104,7 +104,8 @@ __global__ __launch_bounds__(256) void fda_atu_kernel(const Fda b) {
   const double ib = sc->inv_beta, ia = sc->inv_alfa, beta = sc->beta;
   const int rows = b.rows, cols = b.cols;
   double s = 0.0;
-  SMRF_FOR_CELLS(rows, cols) {
+  const LsqrTile tl = lsqr_tile();                      // XCD-aware placement of the walk (lsqr_core.h)
+  SMRF_FOR_CELLS_T(tl, rows, cols, cols) {
     if (!b.hole[i]) continue;
     double y = 0.0;
     if (r >= 1 && has_v(b, r - 1)) {                      // the row above holds this cell as its "down" entry
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void fda_atu_kernel(const Fda b) {
     s += nv * nv;
   }
   const double t = block_sum(s, red);
-  if (threadIdx.x == 0) b.part[blockIdx.y * gridDim.x + blockIdx.x] = t;
+  if (threadIdx.x == 0) b.part[SMRF_TILE_SLOT(tl)] = t;
 }
 
 __global__ void fda_init_alfa(const Fda b) {
@@ -177,7 +178,8 @@ __global__ __launch_bounds__(256) void fda_av_kernel(const Fda b) {
   if (stopped(sc)) return;
   const double ib = sc->inv_beta, ia = sc->inv_alfa, alfa = sc->alfa;
   double s = 0.0;
-  SMRF_FOR_CELLS(b.rows, b.cols) {
+  const LsqrTile tl = lsqr_tile();                      // XCD-aware placement of the walk (lsqr_core.h)
+  SMRF_FOR_CELLS_T(tl, b.rows, b.cols, b.cols) {
     const int cnt = b.cnt[i];
     if (cnt == 0) continue;
     const double nu = fda_row_dot(b, i, r, c, ia) - alfa * (ib * b.u[i]);
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256) void fda_av_kernel(const Fda b) {
     s += cnt * (nu * nu);
   }
   const double t = block_sum(s, red);
-  if (threadIdx.x == 0) b.part[blockIdx.y * gridDim.x + blockIdx.x] = t;
+  if (threadIdx.x == 0) b.part[SMRF_TILE_SLOT(tl)] = t;
 }
 
 // x += t1*w ; w = v_s + t2*w (iteration i) fused with u = A v_s - alfa*u_s (iteration i+1): v is
@@ -197,7 +199,8 @@ __global__ __launch_bounds__(256) void fda_xwav_kernel(const Fda b) {
   if (stopped(sc)) return;
   const double t1 = sc->t1, t2 = sc->t2, ir = sc->inv_rho, ia = sc->inv_alfa, ib = sc->inv_beta, alfa = sc->alfa;
   double sd = 0.0, su = 0.0;
-  SMRF_FOR_CELLS(b.rows, b.cols) {
+  const LsqrTile tl = lsqr_tile();                      // XCD-aware placement of the walk (lsqr_core.h)
+  SMRF_FOR_CELLS_T(tl, b.rows, b.cols, b.cols) {
     if (b.hole[i]) {
       const double ws = b.w[i];
       const double dk = ir * ws;
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(256) void fda_xwav_kernel(const Fda b) {
   }
   const double td = block_sum(sd, red);
   const double tu = block_sum(su, red2);
-  if (threadIdx.x == 0) { b.part[blockIdx.y * gridDim.x + blockIdx.x] = td; b.part[MAXB + blockIdx.y * gridDim.x + blockIdx.x] = tu; }
+  if (threadIdx.x == 0) { b.part[SMRF_TILE_SLOT(tl)] = td; b.part[MAXB + SMRF_TILE_SLOT(tl)] = tu; }
 }
 
 __global__ __launch_bounds__(256) void fda_scatter_kernel(double* __restrict__ A, const Fda b) {

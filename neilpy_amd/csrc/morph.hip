@@ -155,7 +155,7 @@ int disk_filter(DiskArgs<T> a, bool dilate, int impl, hipStream_t stream) {
   if (impl == SMRF_IMPL_RING) {
     if (a.radius > SMRF_RING_MAX_RADIUS)
       return smrf_fail(SMRF_E_UNSUPPORTED, "ring kernels cover radius <= %d (got %d)", SMRF_RING_MAX_RADIUS, a.radius);
-    a.seg = smrf_env_int("SMRF_RING_SEG", 0);   // 0: the launcher sizes segments from its occupancy
+    a.seg = smrf_sw().ring_seg;   // 0: the launcher sizes segments from its occupancy
     return RingFn<T>::call(a, dilate ? SMRF_RING_DILATE : SMRF_RING_ERODE, stream);
   }
   if (impl != SMRF_IMPL_DIRECT) return smrf_fail(SMRF_E_ARG, "unknown impl %d", impl);
@@ -170,7 +170,7 @@ int disk_filter(DiskArgs<T> a, bool dilate, int impl, hipStream_t stream) {
 // next launch (16384^2 fp32, 1 GiB per plane: -1.7 % on the whole progressive_filter; 4096^2, 64 MB: +2 %).  SMRF_NT=0|1 forces it.
 template <typename T>
 int nt_rule(int img_rows, int cols) {
-  const int env = smrf_env_int("SMRF_NT", -1);
+  const int env = smrf_sw().nt;
   if (env >= 0) return env != 0;
   return (size_t)img_rows * (size_t)cols * sizeof(T) >= ((size_t)192 << 20);
 }
@@ -234,7 +234,7 @@ int open_flag_api(const T* last, T* opened, uint8_t* mask, uint8_t* when, double
   a.nan_aware = 0;
   a.nt = nt_rule<T>(img_rows, cols);
   a.dense = mask ? dense : 0;
-  a.seg = smrf_env_int("SMRF_RING_SEG", 0);
+  a.seg = smrf_sw().ring_seg;
   return RingFn<T>::call(a, SMRF_RING_FUSED_OPEN, (hipStream_t)stream);
 }
 
@@ -260,7 +260,7 @@ int chain_flag_api(const T* last, T* opened, uint8_t* mask, uint8_t* when, const
   for (int k = 0; k < n; ++k) { c.thr[k] = thr[k]; c.widx[k] = widx[k]; }
   c.img_rows = img_rows; c.cols = cols; c.ld = ld;
   c.in_row0 = in_row0; c.in_rows = in_rows; c.out_row0 = out_row0; c.out_rows = out_rows;
-  c.seg = smrf_env_int("SMRF_RING_SEG", 0);
+  c.seg = smrf_sw().ring_seg;
   c.nt = nt_rule<T>(img_rows, cols);
   c.dense0 = 0;
   if constexpr (sizeof(T) == 4) return smrf_chain_f32(pat, c, (hipStream_t)stream);
@@ -291,19 +291,17 @@ int progressive_filter_api(const T* Z, int rows, int cols, const int32_t* window
   // carries the scan (it loads every cell of the raster; ChainArgs::nan_flag): it runs as if there were no NaN, the
   // flag is read back after it (the one synchronising readback a separate count would need as well), and in the rare
   // case it is set the call starts over on the NaN-aware two-pass kernels.  Otherwise: one count pass first.
-  const int fuse_mode0 = smrf_env_int("SMRF_FUSED", 1);
-  const bool may_chain = nan_aware < 0 && nwin > 0 && fuse_mode0 != 0 && smrf_env_int("SMRF_CHAIN", 1) != 0 &&
-                         smrf_env_int("SMRF_NAN_RIDE", 1) != 0 &&   // 0: always a separate count pass (A/B runs)
+  const int fuse_mode0 = smrf_sw().fused;
+  const bool may_chain = nan_aware < 0 && nwin > 0 && fuse_mode0 != 0 && smrf_sw().chain != 0 &&
+                         smrf_sw().nan_ride != 0 &&   // 0: always a separate count pass (A/B runs)
                          (impl == SMRF_IMPL_AUTO || impl == SMRF_IMPL_RING);
   const int pat0 = may_chain ? smrf_chain_match((int)sizeof(T), windows, nwin, fuse_mode0 == 2 ? (1ll << 62) : (long long)plane) : -1;
-  unsigned* d_nan = nullptr;                               // the flag of a speculative first launch
-  struct FlagGuard {
-    unsigned*& p; hipStream_t st;
-    ~FlagGuard() { if (p) hipFreeAsync(p, st); }
-  } flag_guard{d_nan, stream};
+  // the flag of a speculative first launch: the first word of the workspace's E plane, which nothing touches before the
+  // first two-pass window's erosion (chained / fused launches write O[0], O[1] only) - no allocation on this path
+  unsigned* d_nan = nullptr;
   if (nan_aware < 0) {
     if (pat0 >= 0 && smrf_chain_halo(pat0) < rows) {
-      SMRF_HIP_CHECK(hipMallocAsync((void**)&d_nan, sizeof(unsigned), stream));
+      d_nan = reinterpret_cast<unsigned*>(E);
       SMRF_HIP_CHECK(hipMemsetAsync(d_nan, 0, sizeof(unsigned), stream));
       nan_aware = 0;
     } else {
@@ -337,14 +335,16 @@ int progressive_filter_api(const T* Z, int rows, int cols, const int32_t* window
   };
   const T* last = Z;
   // small disks: opening + flag in ONE launch, the eroded surface never leaves the CU (morph_fused.h; 10 instead of
-  // 22 B/cell in fp32), and runs of consecutive small windows (1, 2, 3 | 4, 5 | 6, 7 | 8, 9) as ONE launch that only
-  // reads the first window's input and writes the last window's opening (morph_chain.h).  Not for rasters with NaNs
-  // (scipy's NaN rule lives in the two-pass kernels only).
+  // 22 B/cell in fp32), and runs of consecutive small windows (chain.hip's patterns: 1, 2, 3 | 1, 2 | 2, 3 | 4, 5, and the
+  // table-free single launches 4..10) as ONE launch that only reads the first window's input and writes the last window's
+  // opening (morph_chain.h).  Not for rasters with NaNs (scipy's NaN rule lives in the two-pass kernels only) - except that
+  // the FIRST launch of a call with nan_aware < 0 runs speculatively and carries the NaN scan: if it meets a NaN its
+  // results are discarded and the call starts over on the two-pass kernels (below).
   // SMRF_FUSED: 0 = never, 1 = default rule, 2 = every radius that has a fused kernel whatever the raster size (tests);
   // SMRF_CHAIN: 0 = no chains (every window its own launch).
-  const int fuse_mode = smrf_env_int("SMRF_FUSED", 1);
+  const int fuse_mode = smrf_sw().fused;
   const bool fuse_ok0 = (impl == SMRF_IMPL_AUTO || impl == SMRF_IMPL_RING) && fuse_mode != 0;
-  const bool chain_ok0 = smrf_env_int("SMRF_CHAIN", 1) != 0;
+  const bool chain_ok0 = smrf_sw().chain != 0;
   int flip = 0;                                          // which of the two opened planes the next launch writes
   for (int i = 0; i < nwin;) {
     const int r = windows[i];
@@ -353,6 +353,9 @@ int progressive_filter_api(const T* Z, int rows, int cols, const int32_t* window
     const bool fuse_ok = !nan_aware && fuse_ok0;           // (nan_aware can change once: a speculative first launch that met a NaN)
     const bool chain_ok = fuse_ok && chain_ok0;
     const int pat = chain_ok ? smrf_chain_match((int)sizeof(T), windows + i, nwin - i, fuse_mode == 2 ? (1ll << 62) : (long long)plane) : -1;
+    // a speculative first launch was decided on pat0 above: the loop must take exactly that launch, or a NaN raster would
+    // run the NaN-free kernels unscanned
+    if (i == 0 && d_nan && pat != pat0) return smrf_fail(SMRF_E_HIP, "internal: first launch %d is not the one the NaN scan rides in (%d)", pat, pat0);
     if (pat >= 0 && smrf_chain_halo(pat) < rows) {
       const int len = smrf_chain_length(pat);
       ChainArgs<T> c{};
@@ -360,7 +363,7 @@ int progressive_filter_api(const T* Z, int rows, int cols, const int32_t* window
       for (int k = 0; k < len; ++k) { c.thr[k] = thr[i + k]; c.widx[k] = i + k; }
       c.img_rows = rows; c.cols = cols; c.ld = cols;
       c.in_row0 = 0; c.in_rows = rows; c.out_row0 = 0; c.out_rows = rows;
-      c.seg = smrf_env_int("SMRF_RING_SEG", 0);
+      c.seg = smrf_sw().ring_seg;
       c.nt = nt_rule<T>(rows, cols);
       c.dense0 = i == 0;
       c.nan_flag = i == 0 ? d_nan : nullptr;
@@ -372,7 +375,6 @@ int progressive_filter_api(const T* Z, int rows, int cols, const int32_t* window
         unsigned h = 0;
         SMRF_HIP_CHECK(hipMemcpyAsync(&h, d_nan, sizeof(h), hipMemcpyDeviceToHost, stream));
         SMRF_HIP_CHECK(hipStreamSynchronize(stream));
-        SMRF_HIP_CHECK(hipFreeAsync(d_nan, stream));
         d_nan = nullptr;
         if (h) {                                           // start over with scipy's NaN rule (two-pass kernels only)
           nan_aware = 1;

@@ -89,12 +89,99 @@ struct ChainCfg {
 // One stage: the lanes' cells `io` (NP pairs of this lane's column) are already in `buf` (cell R + tid of row p) and a
 // barrier has passed.  Reads the R cells either side, grows the disk's window minima from the own cell, folds the pair
 // into the ring; io <- the two rows each pair completes (input rows - R).
+// Neighbour cells per read group of a stage (0: all 2R reads of a pair at once, the form of R <= 10 in fp32).  The reads of a
+// pair are 4R registers in fp32 and 8R in fp64 when taken at once - what made every fp64 single-window form spill.  In groups
+// of G cells per side, the next group in flight while this one is folded into the growing window, they are 8G (16G)
+// registers whatever R: the fp64 singles of chain.hip (R = 4, 5, 7, 8; 112-160 registers).  The same form for fp32
+// R = 11..14 was built and measured 12-16 % slower than the fused kernels (chain.hip): tuning builds only.
+#ifndef SMRF_CHAIN_GROUP
+#define SMRF_CHAIN_GROUP(T, R) chain_group<T>(R)
+#endif
+template <typename T> constexpr int chain_group(int r) { return sizeof(T) == 4 ? (r >= 11 ? 4 : 0) : (r >= 4 ? 2 : 0); }
+
+// The grouped form of chain_stage: the same cells, the same min / max in the same order (the window grows by one cell per
+// side at a time; a width of the disk is a snapshot of the growing value), hence bit-identical results.
+template <typename T, int R, bool DIL, int NP, int WB, int NACC, int G>
+__device__ __forceinline__ void chain_stage_grouped(typename Vec2<T>::type* const buf, const int tid, T (&acc)[NACC],
+                                                    typename Vec2<T>::type (&io)[NP]) {
+  using S = DiskShape<R>;
+  using T2 = typename Vec2<T>::type;
+  static_assert(NACC >= 2 * R && G >= 1, "ring too short / no group size");
+  constexpr int K = S::K, KR1 = S::kidx(R - 1);
+  constexpr int NGR = (R + G - 1) / G;                     // read groups per pair
+  constexpr int NQ = NP * NGR;                             // ... per stage: one pipeline across the pairs
+  const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(buf + tid);
+  T2 lft[2][G], rgt[2][G];
+  auto issue = [&]<int Q>(std::integral_constant<int, Q>) {
+    constexpr int P = Q / NGR, c0 = (Q % NGR) * G;
+    [&]<int... Cc>(std::integer_sequence<int, Cc...>) {
+      (([&] {
+         if constexpr (c0 + Cc < R) {
+           lft[Q & 1][Cc] = lds_read2<(P * WB + R - 1 - (c0 + Cc)) * (int)sizeof(T2)>(base, T());
+           rgt[Q & 1][Cc] = lds_read2<(P * WB + R + 1 + (c0 + Cc)) * (int)sizeof(T2)>(base, T());
+         }
+       }()), ...);
+    }(std::make_integer_sequence<int, G>{});
+  };
+  issue(std::integral_constant<int, 0>{});
+  auto pair_body = [&]<int P>(std::integral_constant<int, P>) {
+       T ra[K], rb[K];
+       ra[0] = io[P].x;
+       rb[0] = io[P].y;
+       T a = ra[0], b = rb[0];
+       [&]<int... Gi>(std::integer_sequence<int, Gi...>) {
+         (([&] {
+            constexpr int Q = P * NGR + Gi, c0 = Gi * G;
+            if constexpr (Q + 1 < NQ) {
+              constexpr int nxt = ((Q + 1) % NGR + 1) * G <= R ? G : R - ((Q + 1) % NGR) * G;   // cells per side of the next group
+              issue(std::integral_constant<int, Q + 1>{});
+              lds_wait<2 * nxt>();                           // the next group's reads may stay in flight
+            } else {
+              lds_wait<0>();
+            }
+            [&]<int... Cc>(std::integer_sequence<int, Cc...>) {
+              (([&] {
+                 constexpr int c = c0 + Cc;
+                 if constexpr (c < R) {
+                   a = op3<DIL>(a, lft[Q & 1][Cc].x, rgt[Q & 1][Cc].x);
+                   b = op3<DIL>(b, lft[Q & 1][Cc].y, rgt[Q & 1][Cc].y);
+                   // c + 1 cells per side reached: a width of the disk?
+                   [&]<int... Kk>(std::integer_sequence<int, Kk...>) {
+                     (([&] { if constexpr (S::wk(Kk + 1) == c + 1) { ra[Kk + 1] = a; rb[Kk + 1] = b; } }()), ...);
+                   }(std::make_integer_sequence<int, K - 1>{});
+                 }
+               }()), ...);
+            }(std::make_integer_sequence<int, G>{});
+          }()), ...);
+       }(std::make_integer_sequence<int, NGR>{});
+       const T o0 = op2<DIL>(acc[0], ra[0]);                // the two rows this pair completes
+       const T o1 = op3<DIL>(acc[1], ra[KR1], rb[0]);
+       [&]<int... Sl>(std::integer_sequence<int, Sl...>) {  // ring: slot s <- slot s + 2 and this pair (morph_ring.h)
+         (([&] {
+            constexpr int da = R - Sl - 2 < 0 ? -(R - Sl - 2) : R - Sl - 2, db = R - Sl - 1 < 0 ? -(R - Sl - 1) : R - Sl - 1;
+            acc[Sl] = op3<DIL>(acc[Sl + 2], ra[S::kidx(da)], rb[S::kidx(db)]);
+          }()), ...);
+       }(std::make_integer_sequence<int, 2 * R - 2>{});
+       acc[2 * R - 2] = op2<DIL>(ra[0], rb[KR1]);
+       acc[2 * R - 1] = rb[0];
+       io[P].x = o0;
+       io[P].y = o1;
+  };
+  [&]<int... P>(std::integer_sequence<int, P...>) {
+    (pair_body(std::integral_constant<int, P>{}), ...);
+  }(std::make_integer_sequence<int, NP>{});
+}
+
 template <typename T, int R, bool DIL, int NP, int WB, int NACC>
 __device__ __forceinline__ void chain_stage(typename Vec2<T>::type* const buf, const int tid, T (&acc)[NACC],
                                             typename Vec2<T>::type (&io)[NP]) {
   using S = DiskShape<R>;
   using T2 = typename Vec2<T>::type;
   static_assert(NACC >= 2 * R, "ring too short");
+  if constexpr (SMRF_CHAIN_GROUP(T, R) > 0) {
+    chain_stage_grouped<T, R, DIL, NP, WB, NACC, SMRF_CHAIN_GROUP(T, R)>(buf, tid, acc, io);
+    return;
+  }
   constexpr int K = S::K, KR1 = S::kidx(R - 1);
   constexpr bool AHEAD = R <= 4 && NP > 1;               // the next pair's reads in flight while this pair is folded
   const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(buf + tid);   // cell tid = column - R
@@ -370,7 +457,7 @@ int chain_launch(const ChainArgs<T>& a_in, hipStream_t stream) {
     SMRF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), C::TW, LDS));
     resident = std::max(1, nb);
     __atomic_store_n(&resident_of[dev], resident, __ATOMIC_RELEASE);
-    if (smrf_env_int("SMRF_RING_DEBUG", 0))
+    if (smrf_sw().ring_debug)
       fprintf(stderr, "smrf chain: R=%d,%d,%d,%d %s NP=%d LDS=%zu, %d workgroups/CU resident\n", R0, R1, R2, R3,
               sizeof(T) == 4 ? "f32" : "f64", NP, LDS, resident);
   }
@@ -380,7 +467,7 @@ int chain_launch(const ChainArgs<T>& a_in, hipStream_t stream) {
     // three workgroups per resident slot: the workgroups a CU really holds can be fewer than the occupancy query says
     // (chain 4, 5: 2.4 waves per SIMD measured where 4 were expected), and a launch sized for exactly one round then
     // runs a second, mostly empty one; with three the tail is short whatever the residency (chain 4, 5: 1.17 -> 0.87 ms)
-    const int rounds = smrf_env_int("SMRF_CHAIN_ROUNDS", 3);
+    const int rounds = smrf_sw().chain_rounds;
     const int nseg = std::max(1, (rounds * resident * 256 + strips / 2) / strips);
     int seg = (a.out_rows + nseg - 1) / nseg;
     seg = std::max(seg, std::max(32, 4 * C::S));           // a segment re-reads 2S warm-up rows

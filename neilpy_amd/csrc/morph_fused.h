@@ -283,7 +283,7 @@ int fused_launch(const DiskArgs<T>& a_in, hipStream_t stream) {
     SMRF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), TW, LDS));
     resident = std::max(1, nb);
     __atomic_store_n(&resident_of[dev], resident, __ATOMIC_RELEASE);
-    if (smrf_env_int("SMRF_RING_DEBUG", 0))
+    if (smrf_sw().ring_debug)
       fprintf(stderr, "smrf fused: R=%d %s NP=%d LDS=%zu, %d workgroups/CU resident\n", R, sizeof(T) == 4 ? "f32" : "f64", NP,
               LDS, resident);
   }
@@ -291,7 +291,7 @@ int fused_launch(const DiskArgs<T>& a_in, hipStream_t stream) {
   constexpr int TWO = TW - 2 * R;
   const int strips = (a.cols + TWO - 1) / TWO;
   if (a.seg <= 0) {
-    const int rounds = smrf_env_int("SMRF_FUSED_ROUNDS", 1);
+    const int rounds = smrf_sw().fused_rounds;
     const int nseg = std::max(1, (rounds * resident * 256 + strips / 2) / strips);   // one round: every workgroup resident
     int seg = (a.out_rows + nseg - 1) / nseg;
     seg = std::max(seg, std::max(32, 8 * R));             // a segment re-reads 4R warm-up rows

@@ -131,6 +131,15 @@
 #define SMRF_OCC_OVERRIDE(...) SMRF_FORCE_OCC
 #endif
 
+// tools/isa_budget.py builds single instances with -DSMRF_ISA_MARK: comment lines in the assembly that name the phase
+// the instructions after them belong to (the min / max and LDS instructions are volatile asm and keep their order against
+// the marks; address arithmetic may float by a few instructions).  Nothing in a product build.
+#ifdef SMRF_ISA_MARK
+#define SMRF_MARK(s) asm volatile("; SMRF_MARK " s)
+#else
+#define SMRF_MARK(s) do { } while (0)
+#endif
+
 namespace smrf {
 
 // one step down the occupancy ladder the kernels are built for (waves per SIMD)
@@ -807,6 +816,7 @@ __device__ __forceinline__ void ring_consume(typename Vec2<T>::type* const L, co
   const unsigned lds_q = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(L + tid + R);
   // (4) consume: window lookups + ring update, pair by pair
   {
+  SMRF_MARK("consume");
   T2 own[NP];                                            // the lane's own cells (level 0)
 #pragma unroll
   for (int p = 0; p < NP; ++p)
@@ -949,6 +959,7 @@ __device__ __forceinline__ void ring_consume_inplace(typename Vec2<T>::type* con
   constexpr int KR1 = S::kidx(R - 1);
   constexpr int M = R + 1;
   const unsigned lds_q = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(L + tid + R);
+  SMRF_MARK("consume");
   T2 own[NP];
 #pragma unroll
   for (int p = 0; p < NP; ++p)
@@ -1058,6 +1069,7 @@ __device__ __forceinline__ void ring_consume_inplace(typename Vec2<T>::type* con
   {
     constexpr int ROT = (2 * NP) % M;
     if constexpr (ROT != 0) {
+      SMRF_MARK("turn");
       T t[M];
 #pragma unroll
       for (int i = 0; i < M; ++i) t[i] = acc[R - 1 + (i + ROT) % M];
@@ -1182,7 +1194,7 @@ void ring_kernel(const DiskArgs<T> a) {
   const int ystart = ys - R - DELTA;
   RowFold rf(ystart, a.img_rows);                        // tracks the NEXT batch to prefetch
   // buffer addressing of the common cases (SMRF_RING_BUF): descriptors based at the first row of each plane this
-  // workgroup touches there, byte offsets of the lane's columns; the host keeps a segment's span below 4 GiB
+  // workgroup touches there, byte offsets of the lane's columns; the host keeps a segment's span below 2 GiB (ring_launch_np)
   constexpr bool BUF = ring_buf_on<T, R, TW, NP>();
   constexpr bool RARE = C::INPLACE && SMRF_RING_RARE_OPAQUE(T, R);
   const int bi = max(0, ystart - a.in_row0);                       // first band row of `in` a fast-path batch can start at
@@ -1216,6 +1228,7 @@ void ring_kernel(const DiskArgs<T> a) {
     const int l0 = rf.p - a.in_row0;
     if (rf.p + ROWS <= rf.n && l0 >= 0 && l0 + ROWS - 1 <= last_in) {
       // common case: ROWS consecutive rows inside the band, no reflection: one address, row strides
+      SMRF_MARK("prefetch");
       if constexpr (BUF) {
         const unsigned s0 = (unsigned)(l0 - bi) * rowb;
 #pragma unroll
@@ -1256,6 +1269,7 @@ void ring_kernel(const DiskArgs<T> a) {
       }
       }
     } else {
+      SMRF_MARK("rare");
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         int la = rf.at(2 * p) - a.in_row0;
@@ -1282,6 +1296,7 @@ void ring_kernel(const DiskArgs<T> a) {
         }
       }
     }
+    SMRF_MARK("prefetch");
     rf.advance(ROWS);
   };
   // one completed output cell, general form: NaN rule, store, flag step (sparse or dense)
@@ -1340,17 +1355,20 @@ void ring_kernel(const DiskArgs<T> a) {
     if (yob + ROWS <= ye && !a.nan_aware && !a.dense) {
       const int ro0 = yob - a.out_row0;
       if (flag) {
-        if (a.nt) emit_rows(std::true_type{}, std::true_type{}, off0, ro0);
-        else emit_rows(std::false_type{}, std::true_type{}, off0, ro0);
+        if (a.nt) { SMRF_MARK("epilogue:nt1:flag1"); emit_rows(std::true_type{}, std::true_type{}, off0, ro0); }
+        else { SMRF_MARK("epilogue:nt0:flag1"); emit_rows(std::false_type{}, std::true_type{}, off0, ro0); }
       } else {
-        if (a.nt) emit_rows(std::true_type{}, std::false_type{}, off0, ro0);
-        else emit_rows(std::false_type{}, std::false_type{}, off0, ro0);
+        if (a.nt) { SMRF_MARK("epilogue:nt1:flag0"); emit_rows(std::true_type{}, std::false_type{}, off0, ro0); }
+        else { SMRF_MARK("epilogue:nt0:flag0"); emit_rows(std::false_type{}, std::false_type{}, off0, ro0); }
       }
+      SMRF_MARK("epilogue");
     } else {
+      SMRF_MARK("rare");
       const long long off0r = (long long)(yob - a.out_row0) * a.ld + smrf_rare<RARE>(x);
 #pragma unroll
       for (int i = 0; i < ROWS; ++i)
         if (yob + i < ye) emit(yob + i, off0r + (long long)i * a.ld, outv[i], lastv[i]);
+      SMRF_MARK("epilogue");
     }
   };
   auto load_last = [&](int yyb) {
@@ -1360,6 +1378,7 @@ void ring_kernel(const DiskArgs<T> a) {
 #endif
     const int y0 = yyb - R - a.out_row0;
     if (y0 >= 0 && y0 + ROWS <= a.out_rows) {
+      SMRF_MARK("last");
       if constexpr (BUF) {
         const unsigned s0 = (unsigned)(y0 - bl) * rowb;
 #pragma unroll
@@ -1371,6 +1390,7 @@ void ring_kernel(const DiskArgs<T> a) {
         lastv[i] = SMRF_NT_LAST ? __builtin_nontemporal_load(&l0[(long long)i * a.ld]) : l0[(long long)i * a.ld];
       }
     } else {
+      SMRF_MARK("rare");
 #pragma unroll
       for (int i = 0; i < ROWS; ++i) {
         int yo = y0 + i;
@@ -1378,6 +1398,7 @@ void ring_kernel(const DiskArgs<T> a) {
         lastv[i] = a.last[(long long)yo * a.ld + smrf_rare<RARE>(xc)];
       }
     }
+    SMRF_MARK("last");
   };
 
   prefetch();
@@ -1386,6 +1407,7 @@ void ring_kernel(const DiskArgs<T> a) {
     // (1) stage the prefetched rows into this batch's level-0 copy.  The other copy may still be
     //     read by a slower wave (its own cells of the previous batch); the higher levels are only
     //     written after the barrier below, which every wave reaches after its previous consume.
+    SMRF_MARK("stage");
     T2 v[NP][NPOS];
     T2 vh[H::NJ];
 #pragma unroll
@@ -1408,9 +1430,13 @@ void ring_kernel(const DiskArgs<T> a) {
     }
     lds_wait<0>();                                         // the compiler does not count asm stores: complete them before the barrier
     phase_sync();
+    SMRF_MARK("epilogue");
     if (yy0 > ystart) epilogue(yy0 - ROWS);
+    SMRF_MARK("prefetch");
     if (yy0 + ROWS < ye + R) prefetch();
+    SMRF_MARK("last");
     load_last(yy0);
+    SMRF_MARK("build");
 
     if constexpr (BAL) {
       // ring_build_consume with the halo cells as wave-jobs: every wave builds its own 256 cells' worth of each row
@@ -1418,7 +1444,9 @@ void ring_kernel(const DiskArgs<T> a) {
       __builtin_amdgcn_s_setprio(SMRF_RING_BUILD_PRIO);
 #ifndef SMRF_RING_DBG_NOBUILD
       ring_base<T, R, DIL, TW, NP, 1, 0>(L, par, tid, true, v);
+      SMRF_MARK("build:halo");
       ring_base_halo<T, R, DIL, TW, NP>(L, par, hl, vh);
+      SMRF_MARK("build");
       phase_sync();
       if constexpr (C::J > C::JB) {
         ring_upper<T, R, DIL, TW, NP, 1, 0>(L, tid, true, v);
@@ -1432,6 +1460,7 @@ void ring_kernel(const DiskArgs<T> a) {
       ring_build_consume<T, R, DIL, TW, NP, NPOS, 0>(L, par, tid, has_last, v, acc, outv, phase_sync);
     }
   }
+  SMRF_MARK("tail");
   {
     const int nb = (ye + R - ystart + ROWS - 1) / ROWS;
     epilogue(ystart + (nb - 1) * ROWS);
@@ -1465,7 +1494,7 @@ int ring_launch_np(const DiskArgs<T>& a_in, hipStream_t stream, bool probe_only,
                                                               C::LDS_BYTES));
     resident = std::max(1, nb);
     __atomic_store_n(&resident_of[dev], resident, __ATOMIC_RELEASE);
-    if (smrf_env_int("SMRF_RING_DEBUG", 0))
+    if (smrf_sw().ring_debug)
       fprintf(stderr, "smrf ring: R=%d %s%s NP=%d G=%d%s LDS=%zu built for %d waves/SIMD, %d workgroups/CU resident\n", R,
               sizeof(T) == 4 ? "f32" : "f64", DIL ? " dilate" : " erode", NP, C::G, C::INPLACE ? " in-place" : "", C::LDS_BYTES,
               C::OCC, resident);
@@ -1477,7 +1506,7 @@ int ring_launch_np(const DiskArgs<T>& a_in, hipStream_t stream, bool probe_only,
     // (every workgroup resident at once, the longest segments, the fewest re-read halo rows) is
     // the fastest from radius 20 up and as fast as any below (tools/ring_tune.py cur@SMRF_RING_ROUNDS=n);
     // segments stay long enough that the 2R halo rows each one re-reads are a small part
-    const int rounds = smrf_env_int("SMRF_RING_ROUNDS", 1);
+    const int rounds = smrf_sw().ring_rounds;
     const int nseg = std::max(1, (rounds * resident * 256 + strips / 2) / strips);
     int seg = (a.out_rows + nseg - 1) / nseg;
     seg = std::max(seg, std::max(32, 4 * R));
@@ -1512,7 +1541,7 @@ int ring_launch(const DiskArgs<T>& a_in, hipStream_t stream) {
     constexpr int NPI = SMRF_RING_INPLACE_NP(T, R);
     static_assert(NPI != NP, "a dual radius needs two different instances");
     static_assert(RingCfg<T, R, TW, NPI>::INPLACE && !RingCfg<T, R, TW, NP>::INPLACE, "dual instances mixed up");
-    const int mode = smrf_env_int("SMRF_RING_DUAL", -1);    // tests / A-B runs: 0 = shifting ring, 1 = in place, -1 = by rule
+    const int mode = smrf_sw().ring_dual;    // tests / A-B runs: 0 = shifting ring, 1 = in place, -1 = by rule
     int seg = 0;
     if (mode != 0 && a_in.seg <= 0) {
       if (int rc = ring_launch_np<T, R, DIL, NPI>(a_in, stream, true, &seg)) return rc;

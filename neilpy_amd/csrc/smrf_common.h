@@ -30,10 +30,20 @@ __host__ __device__ inline int smrf_fold(int i, int n) {
   return p < n ? p : p2 - 1 - p;
 }
 
-inline int smrf_env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v && *v ? atoi(v) : dflt;
-}
+// The SMRF_* environment switches (developer A/B runs; the parity tests force every launch variant through them), read
+// once by core.hip - smrf_switches_reload() of the C ABI reads them again.  -1 / 0 = "by the library's own rule".
+struct SmrfSwitches {
+  int fused;          // SMRF_FUSED: 0 never, 1 by rule, 2 every radius that has a fused / chained kernel whatever the raster size
+  int chain;          // SMRF_CHAIN: 0 = no chained / table-free launches
+  int nan_ride;       // SMRF_NAN_RIDE: 0 = always a separate NaN count pass
+  int nt;             // SMRF_NT: -1 by plane size, 0 / 1 forced
+  int ring_seg;       // SMRF_RING_SEG: output rows per workgroup (0 = from the occupancy)
+  int ring_dual;      // SMRF_RING_DUAL: -1 by segment length, 0 shifting ring, 1 in-place ring
+  int ring_rounds, fused_rounds, chain_rounds;   // workgroups per resident slot
+  int ring_debug;     // SMRF_RING_DEBUG: print each instance's geometry once
+  int ring_ends;      // SMRF_RING_ENDS: -1 by rule, 0 / 1: the segment-end instances of the ring kernels
+};
+SMRF_HIDDEN const SmrfSwitches& smrf_sw();
 
 // integer floor(sqrt(v)), v >= 0
 __host__ __device__ constexpr int smrf_isqrt(int v) {

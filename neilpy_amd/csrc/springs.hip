@@ -117,24 +117,25 @@ __global__ __launch_bounds__(256) void atu_kernel(const Band b) {
   if (stopped(sc)) return;
   const int rows = b.rows, cols = b.cols;
   const long long ld = b.ld;
+  const LsqrTile tl = lsqr_tile();
   if (!sc->beta_pos) {
     // beta == 0 (u = 0: the exact solution is reached): v and alfa stay as they are (lsqr.py:434-441), but the
     // row-band form's tests still take |dk|^2 from this phase's |w|^2, so that half is written all the same
     if constexpr (WSUM) {
       double sw0 = 0.0;
-      SMRF_FOR_CELLS_P(rows, cols, ld) {
+      SMRF_FOR_CELLS_T(tl, rows, cols, ld) {
         if (!b.hole[i]) continue;
         const double ws = b.w[i];
         sw0 += ws * ws;
       }
       const double tw0 = block_sum(sw0, red2);
-      if (threadIdx.x == 0) b.part[MAXB + blockIdx.y * gridDim.x + blockIdx.x] = tw0;
+      if (threadIdx.x == 0) b.part[MAXB + SMRF_TILE_SLOT(tl)] = tw0;
     }
     return;
   }
   const double ib = sc->inv_beta, ia = sc->inv_alfa, beta = sc->beta;
   double s = 0.0, sw = 0.0;
-  SMRF_FOR_CELLS_P(rows, cols, ld) {
+  SMRF_FOR_CELLS_T(tl, rows, cols, ld) {
     if (!b.hole[i]) continue;
     double y = 0.0;
     if (r > 0 || b.has_above) y = y - ib * b.uv[i - ld];
@@ -147,10 +148,10 @@ __global__ __launch_bounds__(256) void atu_kernel(const Band b) {
     if constexpr (WSUM) { const double ws = b.w[i]; sw += ws * ws; }
   }
   const double t = block_sum(s, red);
-  if (threadIdx.x == 0) b.part[blockIdx.y * gridDim.x + blockIdx.x] = t;
+  if (threadIdx.x == 0) b.part[SMRF_TILE_SLOT(tl)] = t;
   if constexpr (WSUM) {
     const double tw = block_sum(sw, red2);
-    if (threadIdx.x == 0) b.part[MAXB + blockIdx.y * gridDim.x + blockIdx.x] = tw;
+    if (threadIdx.x == 0) b.part[MAXB + SMRF_TILE_SLOT(tl)] = tw;
   }
 }
 
@@ -191,7 +192,8 @@ __global__ __launch_bounds__(256) void av_kernel(const Band b) {
   const int rows = b.rows, cols = b.cols;
   const long long ld = b.ld;
   double s = 0.0;
-  SMRF_FOR_CELLS_P(rows, cols, ld) {
+  const LsqrTile tl = lsqr_tile();
+  SMRF_FOR_CELLS_T(tl, rows, cols, ld) {
     // v[i] is read before the hole tests on purpose: making it (or a per-tile activity byte) conditional turns
     // independent loads into dependent ones and measured 4-10 % SLOWER on 8192^2 at every hole pattern
     // (gpurun_out/r02/lsqr_ab*.log); planes of known-only regions are never touched as it is.
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256) void av_kernel(const Band b) {
     }
   }
   const double t = block_sum(s, red);
-  if (threadIdx.x == 0) b.part[blockIdx.y * gridDim.x + blockIdx.x] = t;
+  if (threadIdx.x == 0) b.part[SMRF_TILE_SLOT(tl)] = t;
 }
 
 __global__ void s_beta(const Band b) {
@@ -233,7 +235,8 @@ __global__ __launch_bounds__(256) void xw_kernel(const Band b) {
   if (stopped(sc)) return;
   const double t1 = sc->t1, t2 = sc->t2, ir = sc->inv_rho, ia = sc->inv_alfa;
   double s = 0.0;
-  SMRF_FOR_CELLS_P(b.rows, b.cols, b.ld) {
+  const LsqrTile tl = lsqr_tile();
+  SMRF_FOR_CELLS_T(tl, b.rows, b.cols, b.ld) {
     if (!b.hole[i]) continue;
     const double ws = b.w[i];
     const double dk = ir * ws;
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256) void xw_kernel(const Band b) {
     s += dk * dk;
   }
   const double t = block_sum(s, red);
-  if (threadIdx.x == 0) b.part[blockIdx.y * gridDim.x + blockIdx.x] = t;
+  if (threadIdx.x == 0) b.part[SMRF_TILE_SLOT(tl)] = t;
 }
 
 // row-band form: red[1] = all-reduced |w|^2 from the ATU phase; |dk|^2 = |w|^2 / rho^2
@@ -263,7 +266,8 @@ __global__ __launch_bounds__(256) void xwav_kernel(const Band b) {
   const int rows = b.rows, cols = b.cols;
   const long long ld = b.ld;
   double sd = 0.0, su = 0.0;
-  SMRF_FOR_CELLS_P(rows, cols, ld) {
+  const LsqrTile tl = lsqr_tile();
+  SMRF_FOR_CELLS_T(tl, rows, cols, ld) {
     const bool h0 = b.hole[i];
     const double v0 = ia * b.v[i];                       // unconditional on purpose (see av_kernel)
     if (h0) {
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(256) void xwav_kernel(const Band b) {
   }
   const double td = block_sum(sd, red);
   const double tu = block_sum(su, red2);
-  if (threadIdx.x == 0) { b.part[blockIdx.y * gridDim.x + blockIdx.x] = td; b.part[MAXB + blockIdx.y * gridDim.x + blockIdx.x] = tu; }
+  if (threadIdx.x == 0) { b.part[SMRF_TILE_SLOT(tl)] = td; b.part[MAXB + SMRF_TILE_SLOT(tl)] = tu; }
 }
 
 __global__ __launch_bounds__(256) void scatter_kernel(double* __restrict__ A, const Band b) {

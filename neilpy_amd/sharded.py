@@ -291,7 +291,13 @@ def progressive_filter_sharded(Z_band, img_rows, windows, thresholds, *, rank=No
             # runs of small windows inside a group as ONE launch (HipBandOps.chain_flag): the margin they eat is the sum of
             # theirs; not with NaNs (no NaN rule there) and not where the group's last window is split edge-first (overlap)
             if (world_size > 1 and not nan_aware and not overlap and hasattr(ops, "chain_len")):
-                k = ops.chain_len(last, [windows[j] for j in grp[gpos - 1:]], img_rows * cols)
+                # sized by the cells THIS launch marches (the band plus its still-valid margin), not by the whole raster: the
+                # longer chains and the table-free R = 9, 10 only pay from 48 Mi cells up (chain.hip, min_cells); and a chain
+                # whose halo is not shorter than the raster has no kernel (smrf_pf_chain_flag_* refuses it): other routes then
+                k = ops.chain_len(last, [windows[j] for j in grp[gpos - 1:]],
+                                  (min(img_rows, b1 + M) - max(0, b0 - M)) * cols)
+                if k >= 1 and sum(2 * windows[j] for j in grp[gpos - 1:gpos - 1 + k]) >= img_rows:
+                    k = 0
                 if k >= 1:
                     members = grp[gpos - 1:gpos - 1 + k]
                     lo, hi = max(0, b0 - M), min(img_rows, b1 + M)

@@ -51,6 +51,27 @@ def gpu_device():
     return torch.device("cuda:0")
 
 
+def switch(monkeypatch, name, value):
+    """set (or with None remove) one of the library's SMRF_* environment switches for the rest of the test and have the
+    library read them again - it reads them once, at load (smrf_switches_reload)"""
+    from neilpy_amd import _lib
+    if value is None:
+        monkeypatch.delenv(name, raising=False)
+    else:
+        monkeypatch.setenv(name, str(value))
+    _lib.reload_switches()
+
+
+@pytest.fixture(autouse=True)
+def _switches_follow_the_environment():
+    """after monkeypatch has restored the environment (it is torn down before this autouse fixture), the library's cached
+    switches are read again, so no test inherits another one's routing"""
+    yield
+    from neilpy_amd import _lib
+    if _lib._lib is not None:
+        _lib.reload_switches()
+
+
 def free_port():
     """a TCP port nobody listens on right now (multi-process tests must not collide on a constant)"""
     import socket

@@ -2,6 +2,8 @@
 import numpy as np
 import pytest
 
+from conftest import switch
+
 pytestmark = pytest.mark.gpu
 
 
@@ -214,11 +216,11 @@ def test_fused_small_disk_opening_equals_two_pass_and_oracle(nz, orc, shape, dty
     Z = (nz.synth_dem(max(shape[1], 8), seed=4, rows=max(shape[0], 8))[:shape[0], :shape[1]] +
          rng.normal(0, .2, shape)).astype(dtype)
     windows = np.array([1, 2, 3, 4, 5, 6, 7, 8, 3, 1, 10, 11, 12, 13, 14, 9])
-    monkeypatch.setenv("SMRF_FUSED", "2")                    # radii 10..14 too, which small rasters do not take by default
+    switch(monkeypatch, "SMRF_FUSED", "2")                    # radii 10..14 too, which small rasters do not take by default
     m1, w1 = nz.progressive_filter(Z, windows, 1, .1, return_when_dropped=True)
-    monkeypatch.setenv("SMRF_FUSED", "0")
+    switch(monkeypatch, "SMRF_FUSED", "0")
     m0, w0 = nz.progressive_filter(Z, windows, 1, .1, return_when_dropped=True)
-    monkeypatch.delenv("SMRF_FUSED")
+    switch(monkeypatch, "SMRF_FUSED", None)
     assert np.array_equal(m1, m0) and np.array_equal(w1, w0)
     if 14 < 4 * min(shape):
         m2, w2 = orc.progressive_filter(Z, windows, 1, .1, return_when_dropped=True)

@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, SAMPLES, free_port, golden, load_sample, unpack, zmin_from_centi
+from conftest import GOLDEN, SAMPLES, free_port, golden, load_sample, switch, unpack, zmin_from_centi
 
 pytestmark = pytest.mark.gpu
 
@@ -536,11 +536,11 @@ def test_flag_threshold_float_boundaries(nz, orc, monkeypatch, route):
     height is the float just below / at / just above thresholds that are and are not float32 numbers must be flagged
     exactly as the oracle flags them, on every route a window can take."""
     for name in ("SMRF_FUSED", "SMRF_CHAIN"):
-        monkeypatch.delenv(name, raising=False)
+        switch(monkeypatch, name, None)
     if route == "chain0":
-        monkeypatch.setenv("SMRF_CHAIN", "0")
+        switch(monkeypatch, "SMRF_CHAIN", "0")
     if route == "fused0":
-        monkeypatch.setenv("SMRF_FUSED", "0")
+        switch(monkeypatch, "SMRF_FUSED", "0")
     impl = 2 if route == "direct" else 0
     for slope in (0.3, 0.75, 0.1, 1e-3, 7.0):              # 0.75 and 7.0 are float32 numbers, the others are not
         for window in (1, 2, 4, 9, 11):

@@ -13,7 +13,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from conftest import golden, unpack
+from conftest import golden, switch, unpack
 from sharded_one_gpu import run_bands
 
 pytestmark = pytest.mark.gpu
@@ -44,18 +44,23 @@ def w50(which, nz):
     return g, Z
 
 
-@pytest.mark.parametrize("fused,chain,dual", [(None, None, None), ("0", None, None), ("2", None, None), ("2", "0", None),
-                                              (None, "0", None), (None, None, "1"), ("0", None, "1")])
-def test_w50_mid_reference_golden(nz, monkeypatch, fused, chain, dual):
+@pytest.mark.parametrize("fused,chain,dual,nt", [(None, None, None, None), ("0", None, None, None), ("2", None, None, None),
+                                                 ("2", "0", None, None), (None, "0", None, None), (None, None, "1", None),
+                                                 ("0", None, "1", None),
+                                                 (None, None, None, "1"), ("0", None, None, "1"), ("2", None, None, "1"),
+                                                 ("2", "0", None, "1"), ("0", None, "1", "1"), (None, None, "1", "1")])
+def test_w50_mid_reference_golden(nz, monkeypatch, fused, chain, dual, nt):
     """default routing (chained small windows, fused, two-pass), two-pass everywhere (SMRF_FUSED=0), every chain / fused
     kernel that exists whatever the raster size (SMRF_FUSED=2), the same without chains (SMRF_CHAIN=0: every small window
     through its own fused launch); SMRF_RING_DUAL=1: the in-place ring instances the 16384^2 benchmark runs on its long
-    segments (csrc/ring_inpl.inc, 17 radii) forced on this raster - erosion and dilation + flag step of each"""
-    for name, val in (("SMRF_FUSED", fused), ("SMRF_CHAIN", chain), ("SMRF_RING_DUAL", dual)):
+    segments (csrc/ring_inpl.inc, 21 radii) forced on this raster - erosion and dilation + flag step of each;
+    SMRF_NT=1: the streaming-store epilogues of the ring, fused and chained kernels, which the library only takes by
+    itself on planes of 192 MiB and up (morph.hip nt_rule: the 16384^2 benchmark), forced on this raster under each routing"""
+    for name, val in (("SMRF_FUSED", fused), ("SMRF_CHAIN", chain), ("SMRF_RING_DUAL", dual), ("SMRF_NT", nt)):
         if val is None:
-            monkeypatch.delenv(name, raising=False)
+            switch(monkeypatch, name, None)
         else:
-            monkeypatch.setenv(name, val)
+            switch(monkeypatch, name, val)
     g, Z = w50("mid", nz)
     windows = g["windows"]
     assert list(windows) == list(range(1, 51))
@@ -77,9 +82,9 @@ def test_w50_row_band_driver(nz, gpu_device, monkeypatch, which, world, chain):
     windows of a group as chained / table-free launches (default) or one fused launch each (SMRF_CHAIN=0)"""
     import torch
     if chain is None:
-        monkeypatch.delenv("SMRF_CHAIN", raising=False)
+        switch(monkeypatch, "SMRF_CHAIN", None)
     else:
-        monkeypatch.setenv("SMRF_CHAIN", chain)
+        switch(monkeypatch, "SMRF_CHAIN", chain)
     g, Z = w50(which, nz)
     Zd = torch.from_numpy(Z).to(gpu_device)
     mask, when, groups = run_bands(nz, Zd, g["windows"], world, return_when_dropped=True)
@@ -113,29 +118,77 @@ def test_dual_ring_instances_vs_oracle(nz, orc, monkeypatch):
     rng = np.random.default_rng(65)
     shape = (130, 520)
     Z = (rng.normal(0, 1, shape).cumsum(0).cumsum(1) * 0.05 + 200 + (rng.random(shape) < 0.05) * rng.uniform(1, 25, shape)).astype(np.float32)
-    for r in (21, 22, 23, 30, 33, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50):
+    for r in (21, 22, 23, 24, 25, 26, 27, 30, 33, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50):
         fp = orc.disk(r)
         we, wd = orc.erosion(Z, fp), orc.dilation(Z, fp)
         for mode in ("0", "1"):
-            monkeypatch.setenv("SMRF_RING_DUAL", mode)
+            switch(monkeypatch, "SMRF_RING_DUAL", mode)
             assert np.array_equal(nz.erosion(Z, radius=r, impl=1), we), (r, mode, "erosion")
             assert np.array_equal(nz.dilation(Z, radius=r, impl=1), wd), (r, mode, "dilation")
-    monkeypatch.delenv("SMRF_RING_DUAL")
+    switch(monkeypatch, "SMRF_RING_DUAL", None)
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_every_radius_vs_oracle(nz, orc, dtype):
-    """ring kernels, every instantiated radius, erosion and dilation, 3 strips wide (about 70 s of oracle per dtype)"""
+def test_every_radius_vs_oracle(nz, orc, dtype, monkeypatch):
+    """ring kernels, every instantiated radius, erosion and dilation, 3 strips wide (about 70 s of oracle per dtype);
+    each with ordinary and with streaming stores (SMRF_NT=0 / 1: the epilogue the 16384^2 benchmark takes)"""
     rng = np.random.default_rng(64)
     shape = (150, 600)
     base = rng.normal(0, 1, shape).cumsum(0).cumsum(1) * 0.05 + 200
     Z = (base + (rng.random(shape) < 0.05) * rng.uniform(1, 25, shape)).astype(dtype)
     for r in range(1, 65):
         fp = orc.disk(r)
-        e = nz.erosion(Z, radius=r, impl=1)
-        assert e.dtype == dtype and np.array_equal(e, orc.erosion(Z, fp)), (r, "erosion")
-        d = nz.dilation(Z, radius=r, impl=1)
-        assert np.array_equal(d, orc.dilation(Z, fp)), (r, "dilation")
+        we, wd = orc.erosion(Z, fp), orc.dilation(Z, fp)
+        for nt in ("0", "1"):
+            switch(monkeypatch, "SMRF_NT", nt)
+            e = nz.erosion(Z, radius=r, impl=1)
+            assert e.dtype == dtype and np.array_equal(e, we), (r, "erosion", nt)
+            d = nz.dilation(Z, radius=r, impl=1)
+            assert np.array_equal(d, wd), (r, "dilation", nt)
+    switch(monkeypatch, "SMRF_NT", None)
+
+
+def test_buffer_segment_clamp_vs_oracle(nz, orc, gpu_device, monkeypatch):
+    """The buffer-addressed ring kernels (csrc/ring_buf.inc) carry a workgroup's row offsets as 32-bit scalars the hardware
+    does not range-check, so ring_launch_np clamps a segment's span below 2 GiB (morph_ring.h, "buffer addressing: a
+    workgroup's row offsets are 32-bit").  On the benchmark rasters that clamp only engages at cfg5 size (32769 columns of
+    fp64 / 16384^2 never), where no oracle reaches.  Here it is forced on a raster the oracle computes in a second: 150 x 600
+    cells held with a row pitch of 8 MiB (ld = 2^21 floats through the C ABI), one segment asked for (SMRF_RING_SEG = all
+    rows), so the unclamped span would be 150 rows = 1.2 GiB + warm-up and the clamped segments run with byte offsets up to
+    ~1.9 GiB; erosion, dilation + flag step, with ordinary and streaming stores."""
+    import ctypes as C
+    import torch
+    from neilpy_amd import _lib
+    lib = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(66)
+    rows, cols, ld = 150, 600, 1 << 21
+    base = rng.normal(0, 1, (rows, cols)).cumsum(0).cumsum(1) * 0.05 + 200
+    Zh = (base + (rng.random((rows, cols)) < 0.05) * rng.uniform(1, 25, (rows, cols))).astype(np.float32)
+    big = lambda dt: torch.zeros((rows, ld), dtype=dt, device=gpu_device)
+    Zd, Ed, Od = big(torch.float32), big(torch.float32), big(torch.float32)
+    Md, Wd = big(torch.uint8), big(torch.uint8)
+    Zd[:, :cols] = torch.from_numpy(Zh).to(gpu_device)
+    switch(monkeypatch, "SMRF_RING_SEG", str(rows))
+    thr = 0.6
+    for r in (15, 21, 29, 38, 49):                            # radii with buffer addressing on (ring_buf.inc), both ring forms
+        fp = orc.disk(r)
+        we = orc.erosion(Zh, fp)
+        wo = orc.dilation(we, fp)
+        want = (Zh - wo).astype(np.float64) > thr
+        for nt in ("0", "1"):
+            switch(monkeypatch, "SMRF_NT", nt)
+            Ed.zero_(); Od.zero_(); Md.zero_(); Wd.zero_()
+            _lib.check(lib.smrf_disk_filter_f32(C.c_void_p(Zd.data_ptr()), C.c_void_p(Ed.data_ptr()), rows, cols, ld, 0, rows,
+                                                0, rows, r, 0, 0, 1, st))
+            assert np.array_equal(Ed[:, :cols].cpu().numpy(), we), (r, nt, "erosion")
+            _lib.check(lib.smrf_pf_dilate_flag_f32(C.c_void_p(Ed.data_ptr()), C.c_void_p(Zd.data_ptr()), C.c_void_p(Od.data_ptr()),
+                                                   C.c_void_p(Md.data_ptr()), C.c_void_p(Wd.data_ptr()), thr, 7, rows, cols, ld,
+                                                   0, rows, 0, rows, r, 0, 1, st))
+            assert np.array_equal(Od[:, :cols].cpu().numpy(), wo), (r, nt, "dilation")
+            assert np.array_equal(Md[:, :cols].cpu().numpy().astype(bool), want), (r, nt, "mask")
+            assert np.array_equal(Wd[:, :cols].cpu().numpy(), want.astype(np.uint8) * 7), (r, nt, "when")
+            assert int(Ed[:, cols:].abs().sum()) == 0 and int(Md[:, cols:].sum()) == 0   # nothing written beyond the raster's columns
 
 
 def test_window_routes(nz, gpu_device, monkeypatch):
@@ -155,16 +208,16 @@ def test_window_routes(nz, gpu_device, monkeypatch):
         return m, [int(v) for v in t["route"]]
 
     for name in ("SMRF_FUSED", "SMRF_CHAIN"):
-        monkeypatch.delenv(name, raising=False)
+        switch(monkeypatch, name, None)
     m0, r0 = run()                                          # a small raster: chains 1-3, singles 4..8, fused none above 8
     assert r0 == [C, C + 1, C + 2, C, C, C, C, C] + [_lib.ROUTE_TWO_PASS] * 8
-    monkeypatch.setenv("SMRF_FUSED", "2")                   # every launch kind that exists, whatever the size
+    switch(monkeypatch, "SMRF_FUSED", "2")                   # every launch kind that exists, whatever the size
     m2, r2 = run()
     assert r2 == [C, C + 1, C + 2, C, C + 1, C, C, C, C, C] + [_lib.ROUTE_FUSED] * 4 + [_lib.ROUTE_TWO_PASS] * 2
-    monkeypatch.setenv("SMRF_CHAIN", "0")
+    switch(monkeypatch, "SMRF_CHAIN", "0")
     m3, r3 = run()
     assert r3 == [_lib.ROUTE_FUSED] * 8 + [_lib.ROUTE_TWO_PASS] + [_lib.ROUTE_FUSED] * 5 + [_lib.ROUTE_TWO_PASS] * 2
-    monkeypatch.setenv("SMRF_FUSED", "0")
+    switch(monkeypatch, "SMRF_FUSED", "0")
     m4, r4 = run()
     assert r4 == [_lib.ROUTE_TWO_PASS] * 16
     assert torch.equal(m0, m2) and torch.equal(m0, m3) and torch.equal(m0, m4)

@@ -17,6 +17,7 @@ Z = torch.from_numpy(neilpy_amd.synth_dem(16384, seed=20240)).cuda()
 win = np.arange(1, 51)
 for mode in ("1", "0", "1", "0"):
     os.environ["SMRF_NAN_RIDE"] = mode
+    neilpy_amd._lib.reload_switches()
     for _ in range(2):
         neilpy_amd.progressive_filter(Z, win, 1, .15)
     ts = []

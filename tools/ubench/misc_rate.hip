@@ -64,13 +64,30 @@ KERNEL(k_min3_f32,
                     "v_min3_f32 %7, %7, %8, %8\n.endr" REGS8);,
        DECL32, a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7)
 
+// round 4: the 64-bit and packed moves (does turning the in-place ring back pair by pair save issue time?)
+KERNEL(k_mov_b64,
+       asm volatile(".rept 16\nv_mov_b64 %0, %8\nv_mov_b64 %1, %8\nv_mov_b64 %2, %8\nv_mov_b64 %3, %8\nv_mov_b64 %4, %8\n"
+                    "v_mov_b64 %5, %8\nv_mov_b64 %6, %8\nv_mov_b64 %7, %8\n.endr" REGS8);,
+       DECL64, (unsigned)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7))
+KERNEL(k_pk_mov_b32,
+       asm volatile(".rept 16\nv_pk_mov_b32 %0, %8, %8\nv_pk_mov_b32 %1, %8, %8\nv_pk_mov_b32 %2, %8, %8\nv_pk_mov_b32 %3, %8, %8\n"
+                    "v_pk_mov_b32 %4, %8, %8\nv_pk_mov_b32 %5, %8, %8\nv_pk_mov_b32 %6, %8, %8\nv_pk_mov_b32 %7, %8, %8\n.endr" REGS8);,
+       DECL64, (unsigned)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7))
+KERNEL(k_min_f32_dpp,
+       asm volatile(".rept 16\nv_min_f32_dpp %0, %8, %0 row_shr:1 row_mask:0xf bank_mask:0xf\nv_min_f32_dpp %1, %8, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                    "v_min_f32_dpp %2, %8, %2 row_shr:1 row_mask:0xf bank_mask:0xf\nv_min_f32_dpp %3, %8, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                    "v_min_f32_dpp %4, %8, %4 row_shr:1 row_mask:0xf bank_mask:0xf\nv_min_f32_dpp %5, %8, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                    "v_min_f32_dpp %6, %8, %6 row_shr:1 row_mask:0xf bank_mask:0xf\nv_min_f32_dpp %7, %8, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n.endr" REGS8);,
+       DECL32, a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7)
+
 typedef void (*kern_t)(unsigned*, int, Stamp*);
 struct Entry { const char* name; kern_t k; };
 
 int main(int argc, char** argv) {
   const Entry entries[] = {{"v_min3_f32", k_min3_f32}, {"v_lshl_add_u64", k_lshl_add_u64}, {"v_mov_b32", k_mov_b32},
                            {"v_sub_f32", k_sub_f32}, {"v_cvt_f64_f32", k_cvt_f64_f32}, {"v_cmp_lt_f64", k_cmp_lt_f64},
-                           {"v_cmp_lt_f32", k_cmp_lt_f32}, {"v_cndmask_b32", k_cndmask}};
+                           {"v_cmp_lt_f32", k_cmp_lt_f32}, {"v_cndmask_b32", k_cndmask}, {"v_mov_b64", k_mov_b64},
+                           {"v_pk_mov_b32", k_pk_mov_b32}, {"v_min_f32_dpp row_shr:1", k_min_f32_dpp}};
   const int iters = 4000;
   unsigned* out;
   Stamp* st;
