@@ -69,8 +69,9 @@ def cpu_baseline(Z_crop, windows, cellsize, slope):
     orc.progressive_filter(Z_crop, windows, cellsize, slope)
     dt = time.perf_counter() - t0
     out = dict(value=Z_crop.size / dt / 1e6, unit="Mcells/s", cores=1, kind="port", seconds=round(dt, 3),
-               sample="oracle/smrf_oracle.py progressive_filter (scipy.ndimage grey_erosion/grey_dilation, "
-                      "disk footprints, 1 thread) on the %dx%d top-left crop of the same DEM, windows 1..%d"
+               sample="a %dx%d CROP (top-left) of the same DEM, windows 1..%d: oracle/smrf_oracle.py progressive_filter "
+                      "(scipy.ndimage grey_erosion/grey_dilation, disk footprints, 1 thread); SURVEY 8d's full procedure at "
+                      "n = 2048 is profiles/r02_cpu_baseline_2048.json (0.0025 Mcells/s, the same rate)"
                       % (Z_crop.shape[0], Z_crop.shape[1], len(windows)))
     # the same oracle on every host core at once (independent tiles; a child process: this one holds the GPU)
     try:
@@ -308,6 +309,8 @@ def main():
         sys.exit(2)
 
     # what a plain device copy of one plane reaches on this GPU (read + write), for context beside the 8 TB/s spec
+    # (torch's copy_; what hand-written streaming kernels reach by access width, grid and plane size is
+    # tools/ubench/stream_rate.hip -> profiles/r04_stream_rate_ubench.md)
     copy_gbps = None
     if rank == 0:
         tmp = torch.empty_like(Z)
@@ -386,6 +389,16 @@ def main():
                          "device_copy_gbps": copy_gbps, "frac_of_device_copy": achieved / copy_gbps,
                          "classes": classes, "window_ms": window_ms},
         }
+        if classes:
+            # the bytes the launches really move (a chain of k windows (8 + 2k) / k B per cell and window, a fused opening 10,
+            # two ring passes 22 in fp32) over the time of the same timed call: the physical counterpart of `frac`, which
+            # credits every window SURVEY 8d's 22 B whatever launch ran it
+            moved = sum(c["bytes_per_cell_window"] * c["windows"] for c in classes.values()) * cells
+            t_cls = sum(c["ms"] for c in classes.values()) * 1e-3
+            out["roofline"]["achieved_moved"] = moved / t_cls / 1e9
+            out["roofline"]["frac_moved"] = moved / t_cls / 1e9 / peak
+            out["roofline"]["frac_convention"] = ("frac / achieved: SURVEY 8d's 5s + 2 B per cell and window for every window; "
+                                                  "frac_moved: the bytes each launch class moves; frac_traffic: FETCH_SIZE + WRITE_SIZE")
         if per_rank is not None:
             out["per_rank"] = per_rank
         if world == 1 and not a.no_secondary and (n, a.windows, a.dtype) == (16384, 50, "f32"):

@@ -14,7 +14,8 @@ struct Pattern { int n; int r[4]; long long min_cells; long long min_cells_f64; 
 // Measured on 16384^2 fp32 against round 2's one fused launch (two ring passes at R = 9) per window, ms
 // (profiles/r03_chain_windows.md): 1, 2, 3: 0.79 against 1.96; 4, 5: 0.84 against 1.42 (on 4096^2 two single launches
 // win: 0.103 against 0.114); 6: 0.55 against 0.76; 7: 0.67 against 0.79; 8: 0.65 against 0.84; 9: 0.72 against 1.07;
-// 10: 0.79 against 0.99; a chain 6, 7 takes 1.31 (two singles 1.22), a chain 8, 9 (172 registers, two workgroups per CU)
+// 10: 0.79 against 0.99; a chain 6, 7 takes 1.31 (two singles 1.22; round 4, built for 3 waves per SIMD - 154-158 registers,
+// no scratch: 1.28 against 1.18, profiles/r04_logs/chain_6_7_ab.log), a chain 8, 9 (172 registers, two workgroups per CU)
 // 3.1 against 2.0: neither exists.
 // Round 4 (grouped neighbour reads, chain_stage_grouped; profiles/r04_chain_grouped.md): fp64 singles exist at R = 4, 5, 7, 8
 // (8192^2: 0.279 against the fused opening's 0.374 ms at R = 4, 0.308 / 0.330 at 5, 0.425 against two ring passes' 0.549 at 7,

@@ -158,10 +158,12 @@ constexpr int ring_occ_drop(int occ, int steps) {
 // that step takes two (three from R = 41) reads of level 2 per side and one or two more min / max, and level 3 is neither
 // built (4 of the 7 reads and 4 of the 8 instructions of the build per cell and row pair) nor held in LDS.  fp32, two-pass
 // windows, 16384^2 / 4096^2 (profiles/r03_logs/jcap2_all_radii.log): -1...-6 % at most radii from 15 to 58; the radii left
-// at 3 lose with it (29, 31, 46, 50; 59 and up spill); the fused kernels (R <= 14) and fp64 keep 3 (R = 14 fused: +24 %).
+// at 3 lose with it (29, 31, 50; 59 and up spill); the fused kernels (R <= 14) and fp64 keep 3 (R = 14 fused: +24 %).
+// Round 4, builds that differ in these two instances only (profiles/r04_logs/jcap2_r46_r50_ab.log): R = 46 -2.9 % at 2
+// (2.206 -> 2.143 ms per window, taken), R = 50 +8.7 % (stays at 3).
 template <typename T> constexpr int ring_tuned_jcap(int r) {
   if (sizeof(T) != 4 || r < 15 || r > 58) return 3;
-  return (r == 29 || r == 31 || r == 46 || r == 50) ? 3 : 2;
+  return (r == 29 || r == 31 || r == 50) ? 3 : 2;
 }
 
 // columns per workgroup per radius: 256 everywhere (512-column workgroups, one per CU, measured within +-1 % of 256 at

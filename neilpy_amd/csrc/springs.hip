@@ -135,17 +135,35 @@ __global__ __launch_bounds__(256) void atu_kernel(const Band b) {
   }
   const double ib = sc->inv_beta, ia = sc->inv_alfa, beta = sc->beta;
   double s = 0.0, sw = 0.0;
-  SMRF_FOR_CELLS_T(tl, rows, cols, ld) {
-    if (!b.hole[i]) continue;
-    double y = 0.0;
-    if (r > 0 || b.has_above) y = y - ib * b.uv[i - ld];
-    if (c > 0) y = y - ib * b.uh[i - 1];
-    if (c + 1 < cols) y = y + ib * b.uh[i];
-    if (r + 1 < rows || b.has_below) y = y + ib * b.uv[i];
-    const double nv = y - beta * (ia * b.v[i]);
-    b.v[i] = nv;
-    s += nv * nv;
-    if constexpr (WSUM) { const double ws = b.w[i]; sw += ws * ws; }
+  // The hole byte decides whether a cell loads anything else; it is requested one row of the walk ahead.  Worth 4 % per
+  // iteration where holes are sparse (10.8 % of the cells: 1.112 -> 1.070 ms on 8193^2), nothing where they are dense.  Same
+  // cells in the same order: every sum is bit-identical.  (Round 4 also built the rows' loads as ONE unconditional batch
+  // behind a wave-wide test - hipcc waits for every conditional load before it issues the next, five round trips per row
+  // here: 2-7 % SLOWER at both densities, profiles/r04_lsqr_traffic.md; eight waves per SIMD already cover the latencies, and
+  // the cells a wave-wide test no longer skips cost traffic.)
+  {
+    const int c = tl.x * 256 + (int)threadIdx.x;
+    if (c < cols) {
+      int r = tl.y;
+      uint8_t h = r < rows ? b.hole[(long long)r * ld + c] : (uint8_t)0;
+      for (; r < rows; r += gridDim.y) {
+        const long long i = (long long)r * ld + c;
+        const int rn = r + (int)gridDim.y;
+        const uint8_t hn = rn < rows ? b.hole[(long long)rn * ld + c] : (uint8_t)0;
+        if (h) {
+          double y = 0.0;
+          if (r > 0 || b.has_above) y = y - ib * b.uv[i - ld];
+          if (c > 0) y = y - ib * b.uh[i - 1];
+          if (c + 1 < cols) y = y + ib * b.uh[i];
+          if (r + 1 < rows || b.has_below) y = y + ib * b.uv[i];
+          const double nv = y - beta * (ia * b.v[i]);
+          b.v[i] = nv;
+          s += nv * nv;
+          if constexpr (WSUM) { const double ws = b.w[i]; sw += ws * ws; }
+        }
+        h = hn;
+      }
+    }
   }
   const double t = block_sum(s, red);
   if (threadIdx.x == 0) b.part[SMRF_TILE_SLOT(tl)] = t;
@@ -267,28 +285,52 @@ __global__ __launch_bounds__(256) void xwav_kernel(const Band b) {
   const long long ld = b.ld;
   double sd = 0.0, su = 0.0;
   const LsqrTile tl = lsqr_tile();
-  SMRF_FOR_CELLS_T(tl, rows, cols, ld) {
-    const bool h0 = b.hole[i];
-    const double v0 = ia * b.v[i];                       // unconditional on purpose (see av_kernel)
-    if (h0) {
-      const double ws = b.w[i];
-      const double dk = ir * ws;
-      b.x[i] = b.x[i] + t1 * ws;
-      b.w[i] = v0 + t2 * ws;
-      sd += dk * dk;
-    }
-    if (c + 1 < cols) {
-      if (h0 | b.hole[i + 1]) {
-        const double nu = (v0 - ia * b.v[i + 1]) - alfa * (ib * b.uh[i]);
-        b.uh[i] = nu;
-        su += nu * nu;
+  // the three hole bytes a cell's tests need are requested one row of the walk ahead (see atu_kernel); same cells, same order
+  {
+    const int c = tl.x * 256 + (int)threadIdx.x;
+    if (c < cols) {
+      const bool has_r = c + 1 < cols;
+      int r = tl.y;
+      uint8_t h0 = 0, h1 = 0, hd = 0;
+      if (r < rows) {
+        const long long i0 = (long long)r * ld + c;
+        h0 = b.hole[i0];
+        if (has_r) h1 = b.hole[i0 + 1];
+        if (r + 1 < rows) hd = b.hole[i0 + ld];
       }
-    }
-    if (r + 1 < rows) {
-      if (h0 | b.hole[i + ld]) {
-        const double nu = (v0 - ia * b.v[i + ld]) - alfa * (ib * b.uv[i]);
-        b.uv[i] = nu;
-        su += nu * nu;
+      for (; r < rows; r += gridDim.y) {
+        const long long i = (long long)r * ld + c;
+        const int rn = r + (int)gridDim.y;
+        uint8_t n0 = 0, n1 = 0, nd = 0;
+        if (rn < rows) {
+          const long long in = (long long)rn * ld + c;
+          n0 = b.hole[in];
+          if (has_r) n1 = b.hole[in + 1];
+          if (rn + 1 < rows) nd = b.hole[in + ld];
+        }
+        const double v0 = ia * b.v[i];                   // unconditional on purpose (see av_kernel)
+        if (h0) {
+          const double ws = b.w[i];
+          const double dk = ir * ws;
+          b.x[i] = b.x[i] + t1 * ws;
+          b.w[i] = v0 + t2 * ws;
+          sd += dk * dk;
+        }
+        if (has_r) {
+          if (h0 | h1) {
+            const double nu = (v0 - ia * b.v[i + 1]) - alfa * (ib * b.uh[i]);
+            b.uh[i] = nu;
+            su += nu * nu;
+          }
+        }
+        if (r + 1 < rows) {
+          if (h0 | hd) {
+            const double nu = (v0 - ia * b.v[i + ld]) - alfa * (ib * b.uv[i]);
+            b.uv[i] = nu;
+            su += nu * nu;
+          }
+        }
+        h0 = n0; h1 = n1; hd = nd;
       }
     }
   }

@@ -1,13 +1,13 @@
 #!/bin/bash
 # Regenerate the measurements kept under profiles/ (run on the GPU box through gpurun):
-#   bash tools/profile_round.sh r03
+#   bash tools/profile_round.sh r04
 # bench.py default run and the 4096^2 / 18-window configuration; the rocprofv3 kernel trace of the benchmark (no PMC child
 # runs inside a traced run: --no-pmc), the two HBM-traffic PMC passes (separate runs, no other trace domain), the SQ
 # counters of every kernel of one call, kernel traces of the full smrf() on 20 M and 100 M points (the LSQR kernels) and of
 # the fp64 progressive_filter, the compute-only time of a 1/8 band, the misc op-rate micro-benchmark.
 # Under rocprofv3 the program after "--" is always python3 / a binary itself (no env, no bash -c).
 set -e
-tag=${1:-r03}
+tag=${1:-r04}
 out=$(pwd)/gpurun_out/$tag
 R=$(pwd)
 mkdir -p $out
@@ -27,4 +27,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_f64 -- python
 cd $R
 python tools/band_compute.py --reps 5 > $out/band_compute.log 2>&1 < /dev/null
 tools/ubench/misc_rate $out/misc_rate.md > $out/misc_rate.log 2>&1
+tools/ubench/stream_rate $out/stream_rate.md > $out/stream_rate.log 2>&1
+# round 4: the LSQR kernels against the counters (FETCH_SIZE / WRITE_SIZE passes) and a kernel trace of one solve
+bash tools/pmc_lsqr.sh $out/pmc_lsqr > $out/pmc_lsqr.log 2>&1
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_lsqr -- python3 $R/tools/pmc_lsqr_run.py > $out/lsqr_trace.log 2> $out/lsqr_trace.err < /dev/null
+cd $R
 find $out -name "*kernel_stats.csv" | head

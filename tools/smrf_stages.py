@@ -7,7 +7,8 @@
 on device-resident points, then the public ``neilpy_amd.smrf`` call is timed as a whole on the same tensors.
 LSQR figures: ``ms_per_iteration`` and ``gbps`` = 106 B x raster cells / that time - the bytes one iteration of the
 matrix-free solver moves over its planes (u two planes, v, w, x float64 read + written where a hole is, plus the hole
-bytes) - so the figure is the kernels' own traffic model, an upper bound on rasters with few holes.
+bytes; the hardware counters read 106.9 B on a raster with 74 % holes, profiles/r04_lsqr_traffic.md) - an
+upper bound on rasters with few holes.
 """
 import argparse
 import json
@@ -84,7 +85,9 @@ def run(points=20_000_000, extent=8192.0, windows=18, cellsize=1.0, seed=20241):
     stages["points"] = points
     stages["Mpoints_per_s"] = points / stages["smrf_total_ms"] / 1e3
     stages["object_points"] = int(out[3].sum().item())          # CUDA tensors in -> CUDA tensors out
-    stages["lsqr_bytes_model"] = "%.0f B x raster cells per iteration (DESIGN 4.3)" % LSQR_BYTES_PER_CELL_ITER
+    stages["lsqr_bytes_model"] = ("%.0f B x raster cells per iteration (DESIGN 4.3); FETCH_SIZE + WRITE_SIZE of one solve on "
+                                  "8193^2 with 74 %% holes: 106.9 B (profiles/r04_lsqr_traffic.md); ms_per_iteration is stage wall "
+                                  "time / iterations, i.e. with the solver's set-up passes and its host polls") % LSQR_BYTES_PER_CELL_ITER
     return stages
 
 
