@@ -20,6 +20,7 @@ ap.add_argument("--pattern", default="random", choices=["random", "blocks", "obj
                      "probability (clustered, as after cutting objects out of a DTM); objects: the cells progressive_filter "
                      "flags on the DEM (windows 1..18) are the holes, as in smrf's second inpaint")
 ap.add_argument("--libs", default="")
+ap.add_argument("--iters", type=int, default=-1, help="iteration limit (timing-only variant builds whose results differ: give every build the same count)")
 a = ap.parse_args()
 import torch  # noqa: E402
 import neilpy_amd  # noqa: E402
@@ -56,7 +57,8 @@ for i in range(a.reps + 1):
         istop, itn, nunk = C.c_int(0), C.c_int64(0), C.c_int64(0)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        rc = f(C.c_void_p(A.data_ptr()), n, n, 1e-6, 1e-6, 1e8, -1, C.byref(istop), C.byref(itn), C.byref(nunk),
+        rc = f(C.c_void_p(A.data_ptr()), n, n, 1e-6 if a.iters < 0 else 0.0, 1e-6 if a.iters < 0 else 0.0, 1e8 if a.iters < 0 else 0.0,
+               a.iters, C.byref(istop), C.byref(itn), C.byref(nunk),
                C.c_void_p(ws.data_ptr()), nbytes, st)
         assert rc == 0
         e1.record()
