@@ -221,3 +221,34 @@ def test_window_routes(nz, gpu_device, monkeypatch):
     m4, r4 = run()
     assert r4 == [_lib.ROUTE_TWO_PASS] * 16
     assert torch.equal(m0, m2) and torch.equal(m0, m3) and torch.equal(m0, m4)
+
+
+def test_window_routes_f64(nz, orc, gpu_device, monkeypatch):
+    """fp64 routing (round 4: table-free single launches at R = 4, 5, 7, 8 with their neighbour reads taken in groups,
+    csrc/morph_chain.h chain_stage_grouped): which launch every window takes, all routes the same bits, and the oracle"""
+    import torch
+    from neilpy_amd import api, _lib
+    Zh = nz.synth_dem(384, seed=5, dtype=np.float64)
+    Z = torch.from_numpy(Zh).to(gpu_device)
+    win = np.arange(1, 11)
+    thr = .15 * (win * 1)
+    C = _lib.ROUTE_CHAIN
+
+    def run():
+        t = {}
+        m, w = api._progressive_filter_device(Z, win, thr, True, nan_aware=0, timing=t)
+        return m, w, [int(v) for v in t["route"]]
+
+    for name in ("SMRF_FUSED", "SMRF_CHAIN"):
+        switch(monkeypatch, name, None)
+    m0, w0, r0 = run()                                      # a small raster: chain 1, 2; fused 3; single 4; fused 5, 6; two passes from 7
+    assert r0 == [C, C + 1, _lib.ROUTE_FUSED, C, _lib.ROUTE_FUSED, _lib.ROUTE_FUSED] + [_lib.ROUTE_TWO_PASS] * 4
+    switch(monkeypatch, "SMRF_FUSED", "2")                  # every launch kind that exists, whatever the size
+    m2, w2, r2 = run()
+    assert r2 == [C, C + 1, _lib.ROUTE_FUSED, C, C, _lib.ROUTE_FUSED, C, C] + [_lib.ROUTE_TWO_PASS] * 2
+    switch(monkeypatch, "SMRF_FUSED", "0")
+    m4, w4, r4 = run()
+    assert r4 == [_lib.ROUTE_TWO_PASS] * 10
+    assert torch.equal(m0, m2) and torch.equal(m0, m4) and torch.equal(w0, w2) and torch.equal(w0, w4)
+    want, want_w = orc.progressive_filter(Zh, win, 1, .15, return_when_dropped=True)
+    assert np.array_equal(m2.cpu().numpy().astype(bool), want) and np.array_equal(w2.cpu().numpy(), want_w)
