@@ -24,10 +24,12 @@ struct Pattern { int n; int r[4]; long long min_cells; long long min_cells_f64; 
 // registers, 3 waves per SIMD) measured 12-16 % SLOWER than the fused kernels (0.99 / 1.01 / 1.08 / 1.14 against 0.85 / 0.89 /
 // 0.96 / 1.02 ms on 16384^2): the cell-by-cell window growth costs R min / max per row and stage where the table costs
 // K - 1 + ~3, and from R = 11 that outweighs the table's two extra barriers.  They do not exist.
+// The fp64 chain 1, 2, 3 (134 registers at one row pair per batch, 3 waves per SIMD): 0.578 against 0.615 ms for chain 1, 2 + the
+// fused R = 3 on 8192^2, slower on 4096^2 and 1024^2 (profiles/r04_logs/chain_123_f64_ab.log): from 48 Mi cells.
 constexpr long long kLarge = 48ll << 20;
 constexpr long long kMid = 16ll << 20;
 constexpr long long kNever = -1;
-constexpr Pattern kPatterns[] = {{3, {1, 2, 3, 0}, 0, kNever}, {2, {1, 2, 0, 0}, 0, 0}, {2, {2, 3, 0, 0}, 0, 0}, {2, {4, 5, 0, 0}, kLarge, kNever},
+constexpr Pattern kPatterns[] = {{3, {1, 2, 3, 0}, 0, kLarge}, {2, {1, 2, 0, 0}, 0, 0}, {2, {2, 3, 0, 0}, 0, 0}, {2, {4, 5, 0, 0}, kLarge, kNever},
                                  {1, {4, 0, 0, 0}, 0, 0}, {1, {5, 0, 0, 0}, 0, kLarge}, {1, {6, 0, 0, 0}, 0, kNever}, {1, {7, 0, 0, 0}, 0, kMid},
                                  {1, {8, 0, 0, 0}, 0, kLarge}, {1, {9, 0, 0, 0}, kLarge, kNever}, {1, {10, 0, 0, 0}, kLarge, kNever}};
 constexpr int kNPatterns = (int)(sizeof(kPatterns) / sizeof(kPatterns[0]));
@@ -50,7 +52,9 @@ int launch(int pat, const ChainArgs<T>& a_in, hipStream_t s) {
       else if constexpr (F64OK) return smrf::chain_launch<T, 1, 3, R, 0, 0, 0>(a, s);                                    \
       else break;
   switch (pat) {
-    case 0: if constexpr (F32) return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 0), SMRF_CHAIN_OCC, 1, 2, 3, 0>(a, s); else break;   // fp32 only: the fp64 form spills
+    case 0:   // fp64: one row pair per batch, built for 3 waves per SIMD (134 registers; at 4 it spills)
+      if constexpr (F32) return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 0), SMRF_CHAIN_OCC, 1, 2, 3, 0>(a, s);
+      else return smrf::chain_launch<T, 1, 3, 1, 2, 3, 0>(a, s);
     case 1: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 1), SMRF_CHAIN_OCC, 1, 2, 0, 0>(a, s);
     case 2: return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 2), SMRF_CHAIN_OCC, 2, 3, 0, 0>(a, s);
     case 3: if constexpr (F32) return smrf::chain_launch<T, SMRF_CHAIN_NP(T, 3), SMRF_CHAIN_OCC, 4, 5, 0, 0>(a, s); else break;   // fp32 only: the fp64 form spills

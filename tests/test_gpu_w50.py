@@ -225,7 +225,8 @@ def test_window_routes(nz, gpu_device, monkeypatch):
 
 def test_window_routes_f64(nz, orc, gpu_device, monkeypatch):
     """fp64 routing (round 4: table-free single launches at R = 4, 5, 7, 8 with their neighbour reads taken in groups,
-    csrc/morph_chain.h chain_stage_grouped): which launch every window takes, all routes the same bits, and the oracle"""
+    csrc/morph_chain.h chain_stage_grouped, and the chain 1, 2, 3 on large rasters): which launch every window takes, all routes
+    the same bits, and the oracle"""
     import torch
     from neilpy_amd import api, _lib
     Zh = nz.synth_dem(384, seed=5, dtype=np.float64)
@@ -245,7 +246,7 @@ def test_window_routes_f64(nz, orc, gpu_device, monkeypatch):
     assert r0 == [C, C + 1, _lib.ROUTE_FUSED, C, _lib.ROUTE_FUSED, _lib.ROUTE_FUSED] + [_lib.ROUTE_TWO_PASS] * 4
     switch(monkeypatch, "SMRF_FUSED", "2")                  # every launch kind that exists, whatever the size
     m2, w2, r2 = run()
-    assert r2 == [C, C + 1, _lib.ROUTE_FUSED, C, C, _lib.ROUTE_FUSED, C, C] + [_lib.ROUTE_TWO_PASS] * 2
+    assert r2 == [C, C + 1, C + 2, C, C, _lib.ROUTE_FUSED, C, C] + [_lib.ROUTE_TWO_PASS] * 2   # chain 1, 2, 3; singles 4, 5, 7, 8
     switch(monkeypatch, "SMRF_FUSED", "0")
     m4, w4, r4 = run()
     assert r4 == [_lib.ROUTE_TWO_PASS] * 10

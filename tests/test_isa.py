@@ -70,6 +70,6 @@ def test_chain_unit_has_no_inflight_use_no_scratch_loops(tmp_path):
     assert check_isa.lds_hazards(text) == []
     assert "ds_read2" not in text and "ds_write2" not in text
     kernels = re.findall(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S)
-    assert len(kernels) == 17                               # 11 fp32 patterns + the two fp64 chains + 4 fp64 singles
+    assert len(kernels) == 18                               # 11 fp32 patterns + three fp64 chains + 4 fp64 singles
     for name, body in kernels:
         assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1)) <= 16, name
