@@ -24,7 +24,6 @@ SmrfSwitches read_switches() {
   s.fused_rounds = env_int("SMRF_FUSED_ROUNDS", 1);
   s.chain_rounds = env_int("SMRF_CHAIN_ROUNDS", 3);
   s.ring_debug = env_int("SMRF_RING_DEBUG", 0);
-  s.ring_ends = env_int("SMRF_RING_ENDS", -1);
   return s;
 }
 SmrfSwitches g_sw = read_switches();                       // at library load; smrf_switches_reload() reads again

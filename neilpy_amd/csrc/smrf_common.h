@@ -41,7 +41,6 @@ struct SmrfSwitches {
   int ring_dual;      // SMRF_RING_DUAL: -1 by segment length, 0 shifting ring, 1 in-place ring
   int ring_rounds, fused_rounds, chain_rounds;   // workgroups per resident slot
   int ring_debug;     // SMRF_RING_DEBUG: print each instance's geometry once
-  int ring_ends;      // SMRF_RING_ENDS: -1 by rule, 0 / 1: the segment-end instances of the ring kernels
 };
 SMRF_HIDDEN const SmrfSwitches& smrf_sw();
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Instruction budget of ring_kernel instances, from the gfx950 assembly (no GPU needed).
 
-    python tools/isa_budget.py --radii 38,39,46,50 [--dilate] [--np 0] [--defs "-DSMRF_RING_UNROLL(T,R)=2"] [--md out.md]
+    python tools/isa_budget.py --radii 38,39,46,50 [--dilate] [--np 0] ["--defs=-DSMRF_RING_JCAP(T,R)=2"] [--md out.md]
 
 Compiles ring_kernel<float, R, DIL, 256, NP> alone with -DSMRF_ISA_MARK (csrc/morph_ring.h: comment lines that name the
 phase of the batch loop the following instructions belong to), takes the batch loop (the backward branch with the longest
@@ -130,7 +130,6 @@ def main():
     ap.add_argument("--np", type=int, default=0)
     ap.add_argument("--defs", default="")
     ap.add_argument("--md", default=None)
-    ap.add_argument("--batches", type=int, default=1, help="batches per trip of the loop (SMRF_RING_TURN_EVERY of the build)")
     a = ap.parse_args()
     defs = [d for d in a.defs.split() if d]
     out = []
@@ -138,7 +137,7 @@ def main():
         for R in [int(v) for v in a.radii.split(",")]:
             text = compile_one(R, a.dilate, a.np, defs, tmp)
             info, counts = analyse(text, a.dilate)
-            rows = 2 * info["np"] * a.batches
+            rows = 2 * info["np"]
             hw, wk = disk(R)
             K = len(wk)
             tot = {k: sum(c.get(k, 0) for c in counts.values()) for k in KINDS}
