@@ -579,3 +579,23 @@ def test_nan_anywhere_is_found_by_the_first_launch(nz, orc, dtype):
     m, w = nz.progressive_filter(base, win, 1, .15, return_when_dropped=True)      # and without one
     m2, w2 = orc.progressive_filter(base, win, 1, .15, return_when_dropped=True)
     assert np.array_equal(m, m2) and np.array_equal(w, w2)
+
+
+def test_sharded_entry_points_over_one_rank_rccl(nz):
+    """the sharded entry points over a REAL RCCL process group of one rank (tools/rccl_single_rank_check.py): process-group
+    creation, barrier, the all-reduces of the three stages, all_to_all_single, and the halo exchange's own primitive - a
+    batch_isend_irecv of a raster's row block - with this rank as its own neighbour; every result equal to the single-device
+    one.  (Two ranks on one device are refused by RCCL: the neighbour exchange between DIFFERENT ranks needs two GPUs.)"""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_single_rank_check.py")], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = r.stdout
+    assert "backend nccl" in out
+    assert "objects 74932 74932 True" in out
+    assert "max |band - single device| 0.0" in out
+    assert "create_dem_sharded equal True True" in out
+    assert "self send/recv of a row block over RCCL equal True" in out

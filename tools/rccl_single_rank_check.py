@@ -15,6 +15,7 @@ import neilpy_amd
 from neilpy_amd import sharded
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
 dist.init_process_group("nccl", device_id=dev)
+torch.manual_seed(11)
 print("backend", dist.get_backend())
 n = 1024
 Z = torch.from_numpy(neilpy_amd.synth_dem(n, seed=3)).to(dev)
@@ -35,4 +36,13 @@ z = torch.rand(200000, dtype=torch.float64, device=dev) * 30
 g1, _e, t1 = sharded.create_dem_sharded(x, y, z, 1.0, "min", rank=0, world_size=1)[:3]
 g0, t0 = neilpy_amd.create_dem(x, y, z, 1.0, "min")
 print("create_dem_sharded equal", bool(torch.equal(torch.nan_to_num(g1, nan=-1.0), torch.nan_to_num(g0, nan=-1.0))), tuple(t1)[:6] == tuple(t0)[:6])
+# the halo exchange's own primitive - batch_isend_irecv of row blocks of a raster - with this rank as its own neighbour (RCCL
+# runs a send and the matching recv of one rank inside a group call as a device copy): the P2P path of sharded._exchange
+last = torch.arange(64 * 1024, dtype=torch.float32, device=dev).reshape(64, 1024)
+recv = torch.zeros((8, 1024), dtype=torch.float32, device=dev)
+ops = [dist.P2POp(dist.isend, last[10:18], 0), dist.P2POp(dist.irecv, recv, 0)]
+for req in dist.batch_isend_irecv(ops):
+    req.wait()
+torch.cuda.synchronize()
+print("self send/recv of a row block over RCCL equal", bool(torch.equal(recv, last[10:18])))
 dist.destroy_process_group()
