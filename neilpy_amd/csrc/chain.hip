@@ -37,6 +37,12 @@ constexpr int kNPatterns = (int)(sizeof(kPatterns) / sizeof(kPatterns[0]));
 #ifndef SMRF_CHAIN_OCC
 #define SMRF_CHAIN_OCC 4       // waves per SIMD the chain kernels are built for (tuning builds override)
 #endif
+// per pattern (fp32 singles; tuning builds override): waves per SIMD a kernel is built for
+// (round 4: the single R = 7, pattern 7, fits 5 waves per SIMD - 0.641 -> 0.583 ms on 16384^2; at 5 the singles from R = 8 up and the chain 4, 5
+// spill, at 3 R = 9, 10 gained on one box and lost on the next: profiles/r04_logs/chain_np_occ_ab.log)
+#ifndef SMRF_CHAIN_OCC_OF
+#define SMRF_CHAIN_OCC_OF(PAT) ((PAT) == 7 ? 5 : SMRF_CHAIN_OCC)
+#endif
 // the grouped fp64 singles hold 112-160 registers: built for 3 waves per SIMD
 template <typename T>
 int launch(int pat, const ChainArgs<T>& a_in, hipStream_t s) {
@@ -48,7 +54,7 @@ int launch(int pat, const ChainArgs<T>& a_in, hipStream_t s) {
   // a single window of radius R: fp32 as round 3 built them; F64OK: the grouped fp64 form exists (NP = 1, 3 waves per SIMD)
 #define SMRF_SINGLE(PAT, R, F64OK)                                                                                        \
     case PAT:                                                                                                            \
-      if constexpr (F32) return smrf::chain_launch<T, SMRF_CHAIN_NP(T, PAT), SMRF_CHAIN_OCC, R, 0, 0, 0>(a, s);         \
+      if constexpr (F32) return smrf::chain_launch<T, SMRF_CHAIN_NP(T, PAT), SMRF_CHAIN_OCC_OF(PAT), R, 0, 0, 0>(a, s);   \
       else if constexpr (F64OK) return smrf::chain_launch<T, 1, 3, R, 0, 0, 0>(a, s);                                    \
       else break;
   switch (pat) {

@@ -59,7 +59,11 @@ SMRF_HIDDEN int smrf_chain_f64(int pattern, const ChainArgs<double>& a, hipStrea
 #ifndef SMRF_CHAIN_NP_ALL
 #define SMRF_CHAIN_NP_ALL 0
 #endif
-#define SMRF_CHAIN_NP(T, PAT) (SMRF_CHAIN_NP_ALL ? SMRF_CHAIN_NP_ALL : (sizeof(T) == 4 ? ((PAT) <= 2 ? 4 : 3) : 1))
+#ifndef SMRF_CHAIN_NP
+// (round 4: the single R = 8, pattern 8, takes 4 - 0.668 -> 0.642 ms on 16384^2; 4 pairs lose or tie at every other single and at the chain 4, 5:
+// profiles/r04_logs/chain_np_occ_ab.log)
+#define SMRF_CHAIN_NP(T, PAT) (SMRF_CHAIN_NP_ALL ? SMRF_CHAIN_NP_ALL : (sizeof(T) == 4 ? ((PAT) <= 2 || (PAT) == 8 ? 4 : 3) : 1))
+#endif
 
 namespace smrf {
 
