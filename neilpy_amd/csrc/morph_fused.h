@@ -51,10 +51,13 @@ constexpr bool fused_lastq(int r) {   // profiles/r03_logs/lastq_ab_f32.log: fp3
 }
 
 // workgroups per CU the kernel is built for: what the two tables' LDS allows, at most 4 (128 registers per lane)
+#ifndef SMRF_FUSED_BLOCKS
+#define SMRF_FUSED_BLOCKS(R) 4
+#endif
 template <typename T, int R, int TW, int NP>
 constexpr int fused_min_blocks() {
   const int by_lds = (int)(160 * 1024 / (2 * RingCfg<T, R, TW, NP>::LDS_BYTES));
-  const int by_regs = R >= 19 ? 2 : R >= 15 ? 3 : 4;       // two rings of 2R registers: 128 per lane no longer hold them from R = 15
+  const int by_regs = R >= 19 ? 2 : R >= 15 ? 3 : SMRF_FUSED_BLOCKS(R);   // two rings of 2R registers: 128 per lane no longer hold them from R = 15
   const int cap = by_lds < by_regs ? by_lds : by_regs;
   return cap < 1 ? 1 : cap;
 }
