@@ -125,6 +125,13 @@
 #ifndef SMRF_RING_INPLACE_NP
 #define SMRF_RING_INPLACE_NP(T, R) ring_tuned_inplace_np<T>(R)
 #endif
+// per-radius overrides of ring_tune.inc's two knobs in single-knob tuning builds (product builds read the tables)
+#ifndef SMRF_RING_OCC_DROP_OF
+#define SMRF_RING_OCC_DROP_OF(T, R) ring_tuned_occ_drop<T>(R)
+#endif
+#ifndef SMRF_RING_NP_MAX_OF
+#define SMRF_RING_NP_MAX_OF(T, R) ring_tuned_np_max<T>(R)
+#endif
 #ifndef SMRF_FORCE_OCC
 #define SMRF_OCC_OVERRIDE(...) __VA_ARGS__
 #else
@@ -397,7 +404,7 @@ struct RingCfg {
   static constexpr int NEED = NEED_BASE + (D - 2) * 4 * G * E;
   static constexpr int OCC_EST = NEED <= 64 ? 8 : NEED <= 96 ? 5 : NEED <= 128 ? 4 : NEED <= 168 ? 3 : NEED <= 264 ? 2 : 1;
   static constexpr int OCC_REG = INPLACE && SMRF_RING_INPLACE_OCC(T, R) > 0 ? SMRF_RING_INPLACE_OCC(T, R)
-                                                                          : ring_occ_drop(OCC_EST, ring_tuned_occ_drop<T>(R));
+                                                                          : ring_occ_drop(OCC_EST, SMRF_RING_OCC_DROP_OF(T, R));
   static constexpr int WAVES = TW / 64;                  // waves per workgroup
   static constexpr int WG_LDS = (int)(160 * 1024 / LDS_BYTES) < 1 ? 1 : (int)(160 * 1024 / LDS_BYTES);
   static constexpr int OCC_LDS = WG_LDS * WAVES / 4 < 1 ? 1 : WG_LDS * WAVES / 4;
@@ -421,7 +428,7 @@ template <typename T, int R, int TW>
 constexpr int ring_np() {
   using C1 = RingCfg<T, R, TW, 1>;
   constexpr int mx = C1::INPLACE && SMRF_RING_INPLACE_NP(T, R) > 0 ? SMRF_RING_INPLACE_NP(T, R)
-                     : sizeof(T) == 4 ? ring_tuned_np_max<T>(R) : (ring_tuned_np_max<T>(R) / 2 < 1 ? 1 : ring_tuned_np_max<T>(R) / 2);
+                     : sizeof(T) == 4 ? SMRF_RING_NP_MAX_OF(T, R) : (ring_tuned_np_max<T>(R) / 2 < 1 ? 1 : ring_tuned_np_max<T>(R) / 2);
   constexpr int want = C1::OCC_REG * 4 / C1::WAVES < 1 ? 1 : C1::OCC_REG * 4 / C1::WAVES;   // workgroups per CU
   if constexpr (mx >= 4) if (RingCfg<T, R, TW, 4>::WG_LDS >= want) return 4;
   if constexpr (mx >= 3) if (RingCfg<T, R, TW, 3>::WG_LDS >= want) return 3;
