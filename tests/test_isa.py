@@ -73,3 +73,26 @@ def test_chain_unit_has_no_inflight_use_no_scratch_loops(tmp_path):
     assert len(kernels) == 18                               # 11 fp32 patterns + three fp64 chains + 4 fp64 singles
     for name, body in kernels:
         assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1)) <= 16, name
+
+
+def test_instruction_budget_of_a_large_disk_instance(tmp_path):
+    """tools/isa_budget.py (profiles/r04_isa_budget.md): the in-place R = 39 erosion instance compiled with
+    phase marks - the consume phase's min / max per 64-cell row is the decomposition's count (R - 1 ring updates + K - 1
+    width steps + 2 completed rows, a few more for the long first step), the table build and the turn-back are what the
+    note says they are, and the instance holds its ring in registers"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_budget
+    R = 39
+    text = isa_budget.compile_one(R, False, 0, [], str(tmp_path))
+    info, counts = isa_budget.analyse(text, False)
+    rows = 2 * info["np"]
+    hw, wk = isa_budget.disk(R)
+    K = len(wk)
+    assert info["np"] == 3 and info["scratch"] == 0 and info["vgpr"] <= 168
+    consume = counts["consume"]["minmax"] / rows
+    assert R + K - 1 <= consume <= R + K + 3, consume            # 63.5 against R + K = 63
+    build = (counts["build"]["minmax"] + counts.get("build:halo", {}).get("minmax", 0)) / rows
+    assert 2.5 <= build <= 4.5, build                           # levels 1, 2 over 256 + 2R staged cells per 256 outputs
+    assert abs(counts["turn"]["mov"] / rows - (R + 1) / rows) < 0.5   # R + 1 v_mov per batch
+    total_valu = sum(c.get(k, 0) for c in counts.values() for k in ("minmax", "mov", "valu_other")) / rows
+    assert total_valu <= R + K + 22, total_valu                 # 82.8 measured; the note's budget table
