@@ -51,6 +51,23 @@ __global__ __launch_bounds__(256) void pass54_rows(V* __restrict__ x, V* __restr
   }
 }
 
+// atu's traffic: three planes in (v, uh, uv), one out (v, in place)
+template <typename V, bool NT>
+__global__ __launch_bounds__(256) void pass31_rows(V* __restrict__ v, const V* __restrict__ uh, const V* __restrict__ uv, int rows,
+                                                   int colsv, double t) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= colsv) return;
+  for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+    const long long i = (long long)r * colsv + c;
+    V a, b, cc;
+    if (NT) { a = __builtin_nontemporal_load(v + i); b = __builtin_nontemporal_load(uh + i); cc = __builtin_nontemporal_load(uv + i); }
+    else { a = v[i]; b = uh[i]; cc = uv[i]; }
+    a = (b + cc) - t * a;
+    if (NT) __builtin_nontemporal_store(a, v + i);
+    else v[i] = a;
+  }
+}
+
 template <typename F>
 double time_ms(F&& launch, int reps = 7) {
   hipEvent_t e0, e1;
@@ -104,6 +121,10 @@ int main(int argc, char** argv) {
     report("5 planes in, 4 out, 8 B / lane, non-temporal", time_ms([&] { hipLaunchKernelGGL((pass54_rows<double, true>), g8, dim3(256), 0, 0, p[0], p[1], p[2], p[3], p[4], rows, cols, 0.5); }), pb);
     report("5 planes in, 4 out, 16 B / lane, solver walk", time_ms([&] { hipLaunchKernelGGL((pass54_rows<d2, false>), g16, dim3(256), 0, 0, (d2*)p[0], (d2*)p[1], (d2*)p[2], (d2*)p[3], (d2*)p[4], rows, cols / 2, 0.5); }), pb);
     report("5 planes in, 4 out, 16 B / lane, non-temporal", time_ms([&] { hipLaunchKernelGGL((pass54_rows<d2, true>), g16, dim3(256), 0, 0, (d2*)p[0], (d2*)p[1], (d2*)p[2], (d2*)p[3], (d2*)p[4], rows, cols / 2, 0.5); }), pb);
+    const double qb = 4.0 * n * 8;
+    report("3 planes in, 1 out (in place), 8 B / lane, solver walk", time_ms([&] { hipLaunchKernelGGL((pass31_rows<double, false>), g8, dim3(256), 0, 0, p[0], p[1], p[2], rows, cols, 0.5); }), qb);
+    report("3 planes in, 1 out (in place), 8 B / lane, non-temporal", time_ms([&] { hipLaunchKernelGGL((pass31_rows<double, true>), g8, dim3(256), 0, 0, p[0], p[1], p[2], rows, cols, 0.5); }), qb);
+    report("3 planes in, 1 out (in place), 16 B / lane, solver walk", time_ms([&] { hipLaunchKernelGGL((pass31_rows<d2, false>), g16, dim3(256), 0, 0, (d2*)p[0], (d2*)p[1], (d2*)p[2], rows, cols / 2, 0.5); }), qb);
     for (int gy : {4096 / 16, 8192 / 16}) {
       const dim3 g(cols / 512, gy);
       char nm[128];
