@@ -6,9 +6,13 @@
 A "step" is one call of the public drop-in ``neilpy_amd.progressive_filter(Z, windows, cellsize,
 slope_threshold)`` (all windows: erosion + dilation + flagging per window, plus the call's own NaN
 scan and bool mask) over the synthetic DEM ``synth_dem(n, seed=20240)`` already resident in HBM.  With N > 1
-(launched by torch.distributed.run, one rank per GPU) the DEM's rows are split into N bands and
-groups of consecutive windows exchange their halo rows with the neighbouring ranks over RCCL
-(neilpy_amd/sharded.py): the problem size is fixed, so ``scaling`` is "strong".  Rank 0 prints ONE JSON line.
+(one rank per GPU) the DEM's rows are split into N bands and groups of consecutive windows exchange their halo rows
+with the neighbouring ranks over RCCL (neilpy_amd/sharded.py): the problem size is fixed, so ``scaling`` is "strong".
+Rank 0 prints ONE JSON line.  ``python bench.py --gpus N`` works both ways: started by ``torch.distributed.run`` (WORLD_SIZE
+in the environment) it is one of the N ranks; started bare it first counts the visible devices in a child process (an
+error JSON on stderr and exit 4 when there are fewer than N), then starts the N ranks itself as fresh child processes
+under ``torch.distributed.run`` on 127.0.0.1, relays the line and leaves with their exit code - the starting process
+never imports torch or touches a GPU.
 
 Timing: W warm-up steps, then K steps between barrier + synchronize on both sides (``ms_per_step_mean`` = that wall
 time / K, max over ranks); every step also sits between two events on the launch stream, ``step_ms`` = the K
@@ -22,7 +26,11 @@ device times (max over ranks per step), ``ms_per_step`` their MEDIAN and ``value
                 fused launches move 10 B/cell per window where the convention credits 22
   classes       one extra step through smrf_progressive_filter_timed_* (an event per window): windows grouped by how
                 they ran, each class priced at the bytes it really moves (fused 2s + 2, chain of k windows (2s + 2k) / k,
-                two-pass 5s + 2 B/cell/window), so no GB/s in this block can exceed the peak
+                two-pass 5s + 2 B/cell/window), so no GB/s in this block can exceed the peak; with the counters
+                (third rocprofv3 --pmc child run: GRBM_GUI_ACTIVE SQ_INSTS_VALU) every class also carries
+                valu_inst_per_cell, shader_clock_ghz and valu_frac = VALU instructions x 4.1 cycles / (1024 SIMDs x
+                clock x the class's time): the fraction of the VALU ISSUE bound, the on-chip bound the large disks sit on
+  secondary_bound  the two-pass class's pair: frac of the VALU issue bound beside its fraction of 8 TB/s
 ``secondary`` (N = 1, after the headline; SURVEY 8d's secondary metric): full device smrf() on 20 M synthetic points
   (per-stage ms, points/s, LSQR ms and GB/s per iteration) and the fp64 progressive_filter 8192^2 windows 1..18 rate
   (fp64 is the dtype the reference's smrf runs in, neilpy.py:1136).
@@ -53,8 +61,8 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--cpu-crop", type=int, default=192, help="crop edge for the CPU baseline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-pmc", action="store_true", help="do not collect roofline.traffic live (two rocprofv3 --pmc child "
-                    "runs, ~1 min); quote profiles/pmc_summary.json instead")
+    ap.add_argument("--no-pmc", action="store_true", help="do not collect roofline.traffic / the VALU counters live (three rocprofv3 "
+                    "--pmc child runs, ~1 min); quote profiles/pmc_summary.json instead")
     ap.add_argument("--no-secondary", action="store_true", help="skip the smrf() / fp64 secondary block")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo stages halos through the host: for rehearsing N>1 ranks on one GPU")
@@ -84,43 +92,80 @@ def cpu_baseline(Z_crop, windows, cellsize, slope):
     return out
 
 
-def pmc_traffic_live(n, windows, dtype, timeout_s=150):
-    """HBM bytes per pass of this workload from the hardware counters, measured now: two child runs of
-    tools/pmc_traffic.py (one progressive_filter step + a calibration read) under ``rocprofv3 --pmc FETCH_SIZE`` and
-    ``--pmc WRITE_SIZE`` - separate passes, --kernel-trace only, as MI355X_MICROARCH's HBM section prescribes - reduced
-    by tools/profile_summary.pmc (reads scaled by the calibration kernel's known byte count).  None when rocprofv3
-    is not there, a pass fails or times out: the caller then quotes the committed summary instead."""
+def pmc_live(n, windows, dtype, timeout_s=150):
+    """Hardware counters of this workload, measured now: three child runs of tools/pmc_traffic.py (one progressive_filter
+    step + a calibration read) under ``rocprofv3 --pmc FETCH_SIZE``, ``--pmc WRITE_SIZE`` and ``--pmc GRBM_GUI_ACTIVE
+    SQ_INSTS_VALU`` - separate passes, --kernel-trace only, as MI355X_MICROARCH's HBM section prescribes.
+    Returns (traffic, valu): ``traffic`` = tools/profile_summary.pmc's record (HBM bytes per pass, reads scaled by the
+    calibration kernel's known byte count); ``valu`` = per launch class the VALU wave-instructions, the GPU-active cycles
+    (GRBM_GUI_ACTIVE is summed over the 8 XCDs) and the kernel time of the counter pass.  Either is None when rocprofv3
+    is not there, a pass fails or times out: the caller then quotes the committed summary / leaves the fields out."""
+    import csv
     import glob
     import importlib.util
+    import re
     import shutil
     import subprocess
     import tempfile
     exe = shutil.which("rocprofv3")
     if exe is None or dtype != "f32":
-        return None
+        return None, None
     spec = importlib.util.spec_from_file_location("profile_summary", os.path.join(ROOT, "tools", "profile_summary.py"))
     ps = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ps)
     tmp = tempfile.mkdtemp(prefix="smrf_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     csvs = {}
+    traffic, valu = None, None
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, counter)
-            r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+        for tag, counters in (("FETCH_SIZE", ["FETCH_SIZE"]), ("WRITE_SIZE", ["WRITE_SIZE"]),
+                              ("VALU", ["GRBM_GUI_ACTIVE", "SQ_INSTS_VALU"])):
+            d = os.path.join(tmp, tag)
+            r = subprocess.run([exe, "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", d, "--",
                                 sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), "--size", str(n),
                                 "--windows", str(windows)], cwd="/tmp", env=env, capture_output=True, text=True,
                                timeout=timeout_s)
             found = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not found:
-                return None
-            csvs[counter] = found[0]
-        rec = ps.pmc(csvs["FETCH_SIZE"], csvs["WRITE_SIZE"], n, windows, None)
-        return rec if rec.get("fetch_calibration") else None
+            if r.returncode == 0 and found:
+                csvs[tag] = found[0]
+        if "FETCH_SIZE" in csvs and "WRITE_SIZE" in csvs:
+            rec = ps.pmc(csvs["FETCH_SIZE"], csvs["WRITE_SIZE"], n, windows, None)
+            traffic = rec if rec.get("fetch_calibration") else None
+        if "VALU" in csvs:
+            valu = {}
+            seen = set()
+            for row in csv.DictReader(open(csvs["VALU"])):
+                k = row["Kernel_Name"]
+                m = re.search(r"chain_kernel<\w+, \d+, \d+, (\d+), (\d+), (\d+), (\d+)", k)
+                if m:
+                    cls = "chain%d" % sum(1 for v in m.groups() if int(v))
+                elif "fused_open_kernel" in k:
+                    cls = "fused"
+                elif "ring_kernel" in k:
+                    cls = "two_pass"
+                else:
+                    continue
+                c = valu.setdefault(cls, {"insts": 0.0, "cycles": 0.0, "ns": 0.0})
+                if row["Counter_Name"] == "SQ_INSTS_VALU":
+                    c["insts"] += float(row["Counter_Value"])
+                elif row["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                    c["cycles"] += float(row["Counter_Value"]) / 8.0
+                if row["Dispatch_Id"] not in seen:
+                    seen.add(row["Dispatch_Id"])
+                    c["ns"] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+            if not valu or any(c["insts"] <= 0 or c["cycles"] <= 0 or c["ns"] <= 0 for c in valu.values()):
+                valu = None
     except Exception:  # noqa: BLE001  (a measurement aid: never fail the bench line over it)
-        return None
+        pass
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+    return traffic, valu
+
+
+# cycles one wave64 min / max (v_min3_f32, v_max3_f32, v_min_f32 ...) occupies a SIMD's issue port on gfx950, measured at every
+# occupancy from 2 to 8 waves per SIMD (profiles/r02_issue_rate_ubench.md; the guide's 2-cycle rate holds for fma / add / mul)
+VALU_CYCLES_PER_MINMAX = 4.1
+SIMDS = 1024                                               # 256 CUs x 4
 
 
 def window_classes(Z, windows, thresholds, cells, elem, peak):
@@ -199,8 +244,59 @@ def secondary(dev):
     return out
 
 
+def fail_line(msg, code, **extra):
+    """an error instead of a bench line: one JSON object on stderr (stdout carries bench lines only), non-zero exit"""
+    print(json.dumps(dict({"error": msg}, **extra)), file=sys.stderr, flush=True)
+    sys.exit(code)
+
+
+def visible_devices():
+    """HIP devices a fresh process of this interpreter sees, counted in a CHILD: the process that starts the ranks never
+    imports torch and never touches the GPU (a parent that holds a HIP context beside N ranks is one more process on the
+    card, and nothing that has initialised the GPU may exec another program on this pool).  None if the count fails."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True,
+                           text=True, timeout=900)
+        return int(r.stdout.strip().splitlines()[-1])
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def self_launch(a, argv):
+    """``python bench.py --gpus N`` with no launcher around it: start the N ranks ourselves - fresh child processes under
+    ``torch.distributed.run`` (one per GPU, rendezvous on 127.0.0.1 at a free port), the same command line - relay rank
+    0's line and leave with the launcher's exit code.  Nothing GPU-related happens in this process."""
+    import socket
+    import subprocess
+    if not a.share_gpu:
+        have = visible_devices()
+        if have is None:
+            fail_line("--gpus %d: could not count the visible HIP devices (is torch importable?)" % a.gpus, 4, n_gpus=a.gpus)
+        if have < a.gpus:
+            fail_line("--gpus %d needs %d visible HIP devices, this host shows %d (use --share-gpu --backend gloo to rehearse "
+                      "the ranks on one device)" % (a.gpus, a.gpus, have), 4, n_gpus=a.gpus, devices_visible=have)
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")         # dmabuf IPC: what RCCL needs between the ranks on this pool
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)      # stderr passes through
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    for ln in lines[-1:]:
+        print(ln, flush=True)
+    if r.returncode == 0 and not lines:
+        fail_line("the %d ranks ended without a bench line" % a.gpus, 5, n_gpus=a.gpus)
+    sys.exit(r.returncode)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a, sys.argv[1:])                          # does not return
     import torch
     import torch.distributed as dist
     import neilpy_amd
@@ -209,10 +305,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 and world != a.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (a.gpus, a.gpus, world))
+    if world != a.gpus:
+        if rank == 0:
+            fail_line("--gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (a.gpus, world), 4, n_gpus=a.gpus)
+        sys.exit(4)
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: neilpy_amd has no CPU fallback")
+        if rank == 0:
+            fail_line("bench.py needs an MI355X: neilpy_amd has no CPU fallback", 4, n_gpus=a.gpus)
+        sys.exit(4)
+    if not a.share_gpu and local_rank >= torch.cuda.device_count():
+        fail_line("rank %d has no device: %d visible for %d ranks (use --share-gpu --backend gloo to rehearse on one)"
+                  % (rank, torch.cuda.device_count(), world), 4, n_gpus=a.gpus)
     if a.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -340,13 +443,13 @@ def main():
             classes, window_ms = window_classes(Z, windows, thresholds, cells, elem, peak)
         traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        live = None
+        live, valu = None, None
         if world == 1 and not a.no_pmc:
             # the timed region is over: release this process's planes first, the child runs need the same HBM
             del mask
             Z = None
             torch.cuda.empty_cache()
-            live = pmc_traffic_live(n, a.windows, a.dtype)
+            live, valu = pmc_live(n, a.windows, a.dtype)
         if live is not None:
             traffic = live["hbm_bytes_per_launch"]
             traffic_source = ("live: two child runs of tools/pmc_traffic.py under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
@@ -389,6 +492,25 @@ def main():
                          "device_copy_gbps": copy_gbps, "frac_of_device_copy": achieved / copy_gbps,
                          "classes": classes, "window_ms": window_ms},
         }
+        if classes and valu:
+            # The on-chip bound beside the HBM one (SURVEY 8d "on-chip secondary bound"): the VALU issue port.  Per class:
+            # thread-level VALU instructions per cell and window (= wave instructions per 64-cell row) from SQ_INSTS_VALU, the
+            # shader clock the counter pass ran at (GRBM_GUI_ACTIVE cycles / kernel time), and valu_frac = instructions x 4.1
+            # cycles (what a min / max costs the issue port; these kernels' VALU work is min / max) / (1024 SIMDs x clock x the
+            # class's time in the TIMED step): the fraction of the VALU issue bound the class runs at.
+            for name, c in classes.items():
+                v = valu.get(name)
+                if not v:
+                    continue
+                clock_hz = v["cycles"] / (v["ns"] * 1e-9)
+                c["valu_inst_per_cell"] = v["insts"] * 64.0 / (cells * c["windows"])
+                c["shader_clock_ghz"] = clock_hz / 1e9
+                c["valu_frac"] = v["insts"] * VALU_CYCLES_PER_MINMAX / (SIMDS * clock_hz * c["ms"] * 1e-3)
+            tp = classes.get("two_pass", {})
+            out["roofline"]["secondary_bound"] = {
+                "bound": "valu_issue", "class": "two_pass", "frac": tp.get("valu_frac"), "hbm_frac": tp.get("frac"),
+                "note": "the dominant class sits between its two bounds: frac of the VALU issue bound (SQ_INSTS_VALU x 4.1 cycles "
+                        "per wave64 min / max over 1024 SIMDs at the measured shader clock) beside its fraction of 8 TB/s"}
         if classes:
             # the bytes the launches really move (a chain of k windows (8 + 2k) / k B per cell and window, a fused opening 10,
             # two ring passes 22 in fp32) over the time of the same timed call: the physical counterpart of `frac`, which

@@ -111,7 +111,9 @@ def load():
 def reload_switches():
     """have the library read its SMRF_* environment switches again (it reads them once, at load): tests and A/B tools
     that change them inside a process"""
-    load().smrf_switches_reload()
+    lib = load()
+    if hasattr(lib, "smrf_switches_reload"):      # an older build under NEILPY_AMD_LIB reads its environment per call
+        lib.smrf_switches_reload()
 
 
 def check(rc):

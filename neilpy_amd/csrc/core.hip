@@ -1,4 +1,5 @@
 // Error reporting and library identification of libsmrf_hip.
+#include <atomic>
 #include <cstring>
 
 #include "smrf_common.h"
@@ -26,10 +27,15 @@ SmrfSwitches read_switches() {
   s.ring_debug = env_int("SMRF_RING_DEBUG", 0);
   return s;
 }
-SmrfSwitches g_sw = read_switches();                       // at library load; smrf_switches_reload() reads again
+// Read ONCE, at library load: a process that sets SMRF_* after importing neilpy_amd changes nothing until it calls
+// smrf_switches_reload() (README "Developer switches").  The switches live in immutable snapshots behind an atomic
+// pointer: a reload publishes a new snapshot and never frees the old one (a few dozen bytes per reload, a test hook), so
+// a launch running on another host thread keeps reading a consistent set; a call that overlaps a reload may see the old
+// set for its first launches and the new one after - routing only, every route gives the same bits.
+std::atomic<const SmrfSwitches*> g_sw{new SmrfSwitches(read_switches())};
 }  // namespace
 
-const SmrfSwitches& smrf_sw() { return g_sw; }
+const SmrfSwitches& smrf_sw() { return *g_sw.load(std::memory_order_acquire); }
 
 int smrf_fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -45,7 +51,7 @@ int smrf_abi_version(void) { return SMRF_ABI_VERSION; }
 
 const char* smrf_last_error(void) { return g_err; }
 
-void smrf_switches_reload(void) { g_sw = read_switches(); }
+void smrf_switches_reload(void) { g_sw.store(new SmrfSwitches(read_switches()), std::memory_order_release); }
 
 int smrf_device_count(void) {
   int n = 0;

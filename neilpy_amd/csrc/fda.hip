@@ -30,6 +30,7 @@ struct Fda {
   double* red;
   Sc* sc;
   int rows, cols;
+  int nxcd;           // XCDs of the device (lsqr_tile's placement)
 };
 
 __device__ __forceinline__ bool has_v(const Fda& b, int r) { return r >= 1 && r <= b.rows - 2; }
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void fda_atu_kernel(const Fda b) {
   const double ib = sc->inv_beta, ia = sc->inv_alfa, beta = sc->beta;
   const int rows = b.rows, cols = b.cols;
   double s = 0.0;
-  const LsqrTile tl = lsqr_tile();                      // XCD-aware placement of the walk (lsqr_core.h)
+  const LsqrTile tl = lsqr_tile(b.nxcd);                      // XCD-aware placement of the walk (lsqr_core.h)
   SMRF_FOR_CELLS_T(tl, rows, cols, cols) {
     if (!b.hole[i]) continue;
     double y = 0.0;
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(256) void fda_av_kernel(const Fda b) {
   if (stopped(sc)) return;
   const double ib = sc->inv_beta, ia = sc->inv_alfa, alfa = sc->alfa;
   double s = 0.0;
-  const LsqrTile tl = lsqr_tile();                      // XCD-aware placement of the walk (lsqr_core.h)
+  const LsqrTile tl = lsqr_tile(b.nxcd);                      // XCD-aware placement of the walk (lsqr_core.h)
   SMRF_FOR_CELLS_T(tl, b.rows, b.cols, b.cols) {
     const int cnt = b.cnt[i];
     if (cnt == 0) continue;
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256) void fda_xwav_kernel(const Fda b) {
   if (stopped(sc)) return;
   const double t1 = sc->t1, t2 = sc->t2, ir = sc->inv_rho, ia = sc->inv_alfa, ib = sc->inv_beta, alfa = sc->alfa;
   double sd = 0.0, su = 0.0;
-  const LsqrTile tl = lsqr_tile();                      // XCD-aware placement of the walk (lsqr_core.h)
+  const LsqrTile tl = lsqr_tile(b.nxcd);                      // XCD-aware placement of the walk (lsqr_core.h)
   SMRF_FOR_CELLS_T(tl, b.rows, b.cols, b.cols) {
     if (b.hole[i]) {
       const double ws = b.w[i];
@@ -267,7 +268,7 @@ int smrf_fda_lsqr_f64(double* d_A, int rows, int cols, double atol, double btol,
   b.x = (double*)(p + L.x); b.v = (double*)(p + L.v); b.w = (double*)(p + L.w); b.u = (double*)(p + L.u);
   b.hole = (uint8_t*)(p + L.hole); b.cnt = (uint8_t*)(p + L.cnt);
   b.part = (double*)(p + L.part); b.red = (double*)(p + L.red); b.sc = (Sc*)(p + L.sc);
-  b.rows = rows; b.cols = cols;
+  b.rows = rows; b.cols = cols; b.nxcd = lsqr_xcd_count();
 
   Sc h{};
   h.atol = atol; h.btol = btol; h.ctol = conlim > 0 ? 1 / conlim : 0.0;
@@ -348,7 +349,7 @@ int smrf_fda_apply_f64(const double* d_A, int rows, int cols, const double* d_v,
   b.x = (double*)(p + L.x); b.v = (double*)(p + L.v); b.w = (double*)(p + L.w); b.u = (double*)(p + L.u);
   b.hole = (uint8_t*)(p + L.hole); b.cnt = (uint8_t*)(p + L.cnt);
   b.part = (double*)(p + L.part); b.red = (double*)(p + L.red); b.sc = (Sc*)(p + L.sc);
-  b.rows = rows; b.cols = cols;
+  b.rows = rows; b.cols = cols; b.nxcd = lsqr_xcd_count();
   Sc h{};
   h.cs2 = -1.0; h.iter_lim = -1;
   h.inv_alfa = 1.0; h.inv_beta = 1.0; h.beta_pos = 1;     // alfa = beta = 0: the kernels compute the bare products

@@ -37,27 +37,31 @@ struct Sc {
   for (int r = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x; r < (rows_); r += gridDim.y) \
     for (long long i = (long long)r * (ld_) + c; c < (cols_) && i >= 0; i = -1)
 
-// XCD-aware placement of the 2-D walk's tiles.  Workgroups are dealt round-robin over the 8 XCDs in dispatch order
-// (id = blockIdx.y * gridDim.x + blockIdx.x, XCD = id % 8), each XCD with its own L2; in the plain walk the tile that owns
-// row r + 1 of a column chunk therefore sits on another XCD than the tile that owns row r, and the stencils' vertical
-// neighbours (v[i + ld], uv[i - ld], the hole bytes) are fetched through two L2s: the hardware counters showed 124.5 B per
-// cell and iteration on 8193^2 where the planes' own traffic is 107 (profiles/r04_lsqr_traffic.md).  Here XCD x takes a
-// contiguous run of tiles in column-chunk-major order (t -> chunk t / gy, row phase t % gy), so a chunk's row phases - which
-// march down the raster together - share one L2.  Placement only: tile (tx, ty) walks exactly the cells block (tx, ty) of
-// the plain walk does and writes its partial sum to the same slot, so every sum is bit-identical.
+// XCD-aware placement of the 2-D walk's tiles.  Workgroups are dealt round-robin over the device's XCDs in dispatch order
+// (id = blockIdx.y * gridDim.x + blockIdx.x, XCD = id % nxcd; 8 on an MI355X in SPX mode), each XCD with its own L2; in the
+// plain walk the tile that owns row r + 1 of a column chunk therefore sits on another XCD than the tile that owns row r, and
+// the stencils' vertical neighbours (v[i + ld], uv[i - ld], the hole bytes) are fetched through two L2s: the hardware
+// counters showed 124.5 B per cell and iteration on 8193^2 where the planes' own traffic is 107
+// (profiles/r04_lsqr_traffic.md).  Here XCD x takes a contiguous run of tiles in column-chunk-major order (t -> chunk t / gy,
+// row phase t % gy), so a chunk's row phases - which march down the raster together - share one L2.  Placement only: tile
+// (tx, ty) walks exactly the cells block (tx, ty) of the plain walk does and writes its partial sum to the same slot, so
+// every sum is bit-identical whatever nxcd is.  nxcd comes from the device (hipDeviceAttributeNumberOfXccs, lsqr_xcd_count
+// below: other partition modes and parts have other counts); nxcd <= 1 is the plain walk.
 #ifndef SMRF_LSQR_XCD
 #define SMRF_LSQR_XCD 1
 #endif
 struct LsqrTile { int x, y; };
-__device__ __forceinline__ LsqrTile lsqr_tile() {
+__device__ __forceinline__ LsqrTile lsqr_tile(int nxcd) {
 #if !SMRF_LSQR_XCD
   return LsqrTile{(int)blockIdx.x, (int)blockIdx.y};
 #endif
+  if (nxcd <= 1) return LsqrTile{(int)blockIdx.x, (int)blockIdx.y};
   const int gx = gridDim.x, gy = gridDim.y, total = gx * gy;
   const int id = blockIdx.y * gx + blockIdx.x;
-  const int xcd = id & 7, slot = id >> 3;
-  // tiles dealt to the XCDs before this one: XCD y gets ceil((total - y) / 8) of them
-  const int q = total >> 3, rem = total & 7;
+  int xcd, slot, q, rem;
+  if (nxcd == 8) { xcd = id & 7; slot = id >> 3; q = total >> 3; rem = total & 7; }
+  else { xcd = id % nxcd; slot = id / nxcd; q = total / nxcd; rem = total % nxcd; }
+  // tiles dealt to the XCDs before this one: XCD y gets ceil((total - y) / nxcd) of them
   const int t = xcd * q + (xcd < rem ? xcd : rem) + slot;
   return LsqrTile{t / gy, t % gy};
 }
@@ -66,6 +70,19 @@ __device__ __forceinline__ LsqrTile lsqr_tile() {
   for (int r = (tl_).y, c = (tl_).x * 256 + threadIdx.x; r < (rows_); r += gridDim.y)       \
     for (long long i = (long long)r * (ld_) + c; c < (cols_) && i >= 0; i = -1)
 #define SMRF_TILE_SLOT(tl_) ((tl_).y * gridDim.x + (tl_).x)
+
+// XCDs of the current device (cached per device; 1 = plain walk when the runtime cannot tell)
+inline int lsqr_xcd_count() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 1; }
+  int n = __atomic_load_n(&cached[dev], __ATOMIC_ACQUIRE);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 1; }
+    __atomic_store_n(&cached[dev], n, __ATOMIC_RELEASE);
+  }
+  return n;
+}
 
 __device__ __forceinline__ double block_sum(double s, double* red) {
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);

@@ -459,7 +459,11 @@ int smrf_pf_open_flag_f64(const double* d_last, double* d_opened, uint8_t* d_mas
 }
 int smrf_pf_chain_length(int elem_size, const int32_t* h_radii, int n, int64_t raster_cells) {
   if (!h_radii || n < 1) return 0;
-  const int pat = smrf_chain_match(elem_size, h_radii, n, (long long)raster_cells);
+  // the same switches smrf_progressive_filter_* routes by (read once at load, smrf_switches_reload): SMRF_CHAIN=0 or
+  // SMRF_FUSED=0 = no chained / table-free launches, SMRF_FUSED=2 = every pattern whatever the raster size
+  const SmrfSwitches& sw = smrf_sw();
+  if (sw.chain == 0 || sw.fused == 0) return 0;
+  const int pat = smrf_chain_match(elem_size, h_radii, n, sw.fused == 2 ? (1ll << 62) : (long long)raster_cells);
   return pat < 0 ? 0 : smrf_chain_length(pat);
 }
 int smrf_pf_chain_flag_f32(const float* d_last, float* d_opened, uint8_t* d_mask, uint8_t* d_when_dropped,

@@ -36,6 +36,7 @@ struct Band {
   Sc* sc;
   int rows, cols, has_above, has_below;
   long long ld;       // cells between plane rows (>= cols; the raster A itself is always cols apart)
+  int nxcd;           // XCDs of the device (lsqr_tile's placement; from the runtime, 1 = plain walk)
 };
 
 
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void atu_kernel(const Band b) {
   if (stopped(sc)) return;
   const int rows = b.rows, cols = b.cols;
   const long long ld = b.ld;
-  const LsqrTile tl = lsqr_tile();
+  const LsqrTile tl = lsqr_tile(b.nxcd);
   if (!sc->beta_pos) {
     // beta == 0 (u = 0: the exact solution is reached): v and alfa stay as they are (lsqr.py:434-441), but the
     // row-band form's tests still take |dk|^2 from this phase's |w|^2, so that half is written all the same
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256) void av_kernel(const Band b) {
   const int rows = b.rows, cols = b.cols;
   const long long ld = b.ld;
   double s = 0.0;
-  const LsqrTile tl = lsqr_tile();
+  const LsqrTile tl = lsqr_tile(b.nxcd);
   SMRF_FOR_CELLS_T(tl, rows, cols, ld) {
     // v[i] is read before the hole tests on purpose: making it (or a per-tile activity byte) conditional turns
     // independent loads into dependent ones and measured 4-10 % SLOWER on 8192^2 at every hole pattern
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(256) void xw_kernel(const Band b) {
   if (stopped(sc)) return;
   const double t1 = sc->t1, t2 = sc->t2, ir = sc->inv_rho, ia = sc->inv_alfa;
   double s = 0.0;
-  const LsqrTile tl = lsqr_tile();
+  const LsqrTile tl = lsqr_tile(b.nxcd);
   SMRF_FOR_CELLS_T(tl, b.rows, b.cols, b.ld) {
     if (!b.hole[i]) continue;
     const double ws = b.w[i];
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256) void xwav_kernel(const Band b) {
   const int rows = b.rows, cols = b.cols;
   const long long ld = b.ld;
   double sd = 0.0, su = 0.0;
-  const LsqrTile tl = lsqr_tile();
+  const LsqrTile tl = lsqr_tile(b.nxcd);
   // the three hole bytes a cell's tests need are requested one row of the walk ahead (see atu_kernel); same cells, same order
   {
     const int c = tl.x * 256 + (int)threadIdx.x;
@@ -396,6 +397,7 @@ Band band_of(void* ws, int rows, int cols, long long ld, int has_above, int has_
   b.red = (double*)(p + L.red);
   b.sc = (Sc*)(p + L.sc);
   b.rows = rows; b.cols = cols; b.ld = ld; b.has_above = has_above; b.has_below = has_below;
+  b.nxcd = lsqr_xcd_count();
   return b;
 }
 enum Phase {

@@ -72,10 +72,8 @@ class HipBandOps:
     def chain_len(self, t, radii, raster_cells):
         """how many of the windows at the head of ``radii`` one chained / table-free launch takes on a raster of this size
         (csrc/morph_chain.h; 0 = none)"""
-        import os
         import torch
-        if os.environ.get("SMRF_CHAIN") == "0":              # as in smrf_progressive_filter_*: every small window its own launch
-            return 0
+        # (the library applies its own SMRF_CHAIN / SMRF_FUSED switches here, the ones smrf_progressive_filter_* routes by)
         r = np.ascontiguousarray(np.asarray(radii[:4], dtype=np.int32))
         return int(self.lib.smrf_pf_chain_length(4 if t.dtype == torch.float32 else 8, r.ctypes.data_as(C.c_void_p), int(r.size),
                                                  int(raster_cells)))
@@ -207,6 +205,8 @@ def progressive_filter_sharded(Z_band, img_rows, windows, thresholds, *, rank=No
     rmax = max(windows) if windows else 0
     min_band = min(band_rows(img_rows, world_size, k)[1] - band_rows(img_rows, world_size, k)[0]
                    for k in range(world_size))
+    max_band = max(band_rows(img_rows, world_size, k)[1] - band_rows(img_rows, world_size, k)[0]
+                   for k in range(world_size))
     if world_size > 1 and min_band < 2 * rmax:
         raise ValueError("row bands of %d rows are shorter than the 2*%d halo rows a window needs; "
                          "use fewer ranks for this raster" % (min_band, rmax))
@@ -291,11 +291,13 @@ def progressive_filter_sharded(Z_band, img_rows, windows, thresholds, *, rank=No
             # runs of small windows inside a group as ONE launch (HipBandOps.chain_flag): the margin they eat is the sum of
             # theirs; not with NaNs (no NaN rule there) and not where the group's last window is split edge-first (overlap)
             if (world_size > 1 and not nan_aware and not overlap and hasattr(ops, "chain_len")):
-                # sized by the cells THIS launch marches (the band plus its still-valid margin), not by the whole raster: the
-                # longer chains and the table-free R = 9, 10 only pay from 48 Mi cells up (chain.hip, min_cells); and a chain
-                # whose halo is not shorter than the raster has no kernel (smrf_pf_chain_flag_* refuses it): other routes then
-                k = ops.chain_len(last, [windows[j] for j in grp[gpos - 1:]],
-                                  (min(img_rows, b1 + M) - max(0, b0 - M)) * cols)
+                # sized by the cells a launch of this group marches (a band plus its still-valid margin), not by the whole
+                # raster: the longer chains and the table-free R = 9, 10 only pay from 48 Mi cells up (chain.hip, min_cells).
+                # The SAME figure on every rank - the longest band with a two-sided margin - so that all ranks route a
+                # window the same way (an edge rank's one-sided margin would otherwise put it on the other side of a size
+                # threshold than its neighbour; every route gives the same bits, but the ranks' launches should not differ).
+                # A chain whose halo is not shorter than the raster has no kernel (smrf_pf_chain_flag_* refuses it).
+                k = ops.chain_len(last, [windows[j] for j in grp[gpos - 1:]], min(img_rows, max_band + 2 * M) * cols)
                 if k >= 1 and sum(2 * windows[j] for j in grp[gpos - 1:gpos - 1 + k]) >= img_rows:
                     k = 0
                 if k >= 1:

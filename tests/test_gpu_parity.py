@@ -345,11 +345,14 @@ def test_sharded_two_ranks_on_one_gpu(nz, tmp_path):
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common,
                          capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"),
-                          "--gpus", "2", "--backend", "gloo", "--share-gpu"] + common,
-                         capture_output=True, text=True, timeout=600)
+    # NO launcher and no WORLD_SIZE in the environment: bench.py starts its own two ranks (fresh children under
+    # torch.distributed.run), relays rank 0's line and its exit code
+    bare_env = {k: v for k, v in os.environ.items()
+                if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu"]
+                         + common, capture_output=True, text=True, timeout=600, env=bare_env)
     assert two.returncode == 0, two.stderr[-2000:]
+    assert len([l for l in two.stdout.splitlines() if l.startswith("{")]) == 1      # ONE line
     j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
     assert j2["n_gpus"] == 2 and j1["config"]["object_cells"] == j2["config"]["object_cells"]
@@ -366,6 +369,23 @@ def test_sharded_two_ranks_on_one_gpu(nz, tmp_path):
     for pr in j2["per_rank"]:
         assert pr["exchanges"] == sh["exchanges_per_step"] and pr["exchange_ms"] > 0 and pr["compute_ms"] > 0
         assert pr["exchange_bytes_sent"] == sum(sh["halo_rows_per_exchange"]) * 1024 * 4
+
+
+def test_bench_bare_multi_gpu_preflight(nz):
+    """`python bench.py --gpus N` on a host with fewer than N devices: an error JSON on stderr, exit 4, no line, before
+    any rank is started (the count is made in a child process; the starting process never touches the GPU)"""
+    import json
+    import subprocess
+    import sys
+    import torch
+    from conftest import ROOT
+    want = torch.cuda.device_count() + 1
+    bare_env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(want), "--size", "1024", "--windows", "12"],
+                       capture_output=True, text=True, timeout=600, env=bare_env)
+    assert r.returncode == 4 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    err = json.loads([l for l in r.stderr.splitlines() if l.startswith("{")][-1])
+    assert err["n_gpus"] == want and err["devices_visible"] == want - 1 and "needs" in err["error"]
 
 
 def test_bench_two_ranks_nccl_needs_two_devices(nz):

@@ -38,3 +38,24 @@ def test_progressive_filter_rejects_list_windows_like_reference():
     import neilpy_amd
     with pytest.raises(TypeError):
         neilpy_amd.progressive_filter(np.zeros((4, 4), np.float32), [1, 2], cellsize=.5)
+
+
+def test_bench_bare_multi_gpu_refuses_without_devices():
+    """`python bench.py --gpus N` with no launcher on a host that shows fewer than N devices (64 here: more than any host
+    has): exit 4, an error JSON on stderr, nothing on stdout - and the starting process never imports torch itself"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 4 and r.stdout.strip() == ""
+    err = json.loads([ln for ln in r.stderr.splitlines() if ln.startswith("{")][-1])
+    assert err["n_gpus"] == 64 and err["devices_visible"] < 64 and "needs 64 visible HIP devices" in err["error"]
+    # a launcher that started another number of ranks than --gpus says is refused the same way
+    env2 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       timeout=900, env=env2)
+    assert r.returncode == 4 and "started 3 ranks" in r.stderr

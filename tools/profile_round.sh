@@ -26,6 +26,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_smrf100 -- py
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_f64 -- python3 $R/tools/window_ab.py --shapes 8192x8192 --windows 50 --dtype f64 --fused 0 --reps 3 > $out/f64_windows.log 2> $out/f64.err < /dev/null
 cd $R
 python tools/band_compute.py --reps 5 > $out/band_compute.log 2>&1 < /dev/null
+# the micro-benchmarks are built from their sources here (no binary is tracked: ADVICE r4)
+for u in misc_rate stream_rate; do
+  hipcc --offload-arch=gfx950 -O3 tools/ubench/$u.hip -o tools/ubench/$u
+done
 tools/ubench/misc_rate $out/misc_rate.md > $out/misc_rate.log 2>&1
 tools/ubench/stream_rate $out/stream_rate.md > $out/stream_rate.log 2>&1
 # round 4: the LSQR kernels against the counters (FETCH_SIZE / WRITE_SIZE passes) and a kernel trace of one solve
