@@ -160,6 +160,7 @@ constexpr int ring_occ_drop(int occ, int steps) {
 #include "ring_inc.inc"
 #include "ring_inpl.inc"
 #include "ring_buf.inc"
+#include "ring_fuse.inc"
 // Highest table level of the incremental widths per radius (RingCfg::INC, SMRF_RING_JCAP).  Level 3 (eight cells per
 // read) is only ever read for the FIRST width step of a disk (isqrt(2R - 1) cells: 5..11 for R = 15..64); with the cap at 2
 // that step takes two (three from R = 41) reads of level 2 per side and one or two more min / max, and level 3 is neither
@@ -261,6 +262,74 @@ __device__ __forceinline__ void op3_acc(float& acc, float b, float c) {
 template <bool DIL>
 __device__ __forceinline__ void op3_acc(double& acc, double b, double c) { acc = op2<DIL>(op2<DIL>(acc, b), c); }
 
+// The window steps of one lookup group as ONE asm statement (fp32, one read per side for every width of the group): width
+// k's two minima grown from width k-1's, N widths chained,
+//     x[i] = op3(x[i-1], x[i], u[i]),  y[i] = op3(y[i-1], y[i], w[i])        (x[-1] = a0, y[-1] = b0)
+// in place in the registers the first read of every width arrived in ({x[i], y[i]} = the ds_read_b64 of the window's left
+// end, {u[i], w[i]} the one of its right end).  Written one op3 per asm statement, every step that reads the one before it
+// costs an `s_nop 0`: hipcc counts no wait states for asm statements (they have no known length) and assumes gfx950's
+// dst_sel forwarding hazard between an asm that writes a register and the next asm that reads it - two to three nops per
+// group beside 12-14 min / max (15 per 64-cell row at R = 50).  Inside one statement nothing is inserted, and the
+// hardware interlocks ordinary VALU results by itself.  Bit-identical (same instructions, same operand order).
+// Per radius and instance kind (ring_fuse.inc, written by tools/ring_fuse_inc.py from the compiled instances' register
+// counts and same-process timings): bit 0 = the fused window steps, bit 1 = the ring slots a group releases are updated one
+// group LATE, after the next group's window steps - they then read registers written before that group's (real)
+// s_waitcnt and need no nop either, at the price of one more group's widths staying live.
+#ifndef SMRF_RING_FUSE_MODE
+#define SMRF_RING_FUSE_MODE(T, R, INPL) ring_tuned_fuse<T>(R, INPL)
+#endif
+// (A first form tied each result to the register its left read arrived in - "+v" on a copy of the ds_read's half - and
+// failed on the GPU at a dozen radii: hipcc materialised some of those copies as real v_mov instructions and scheduled
+// them above the s_waitcnt, reading a register the LDS was still filling.  Nothing but asm statements may read a ds_read's
+// destination, and none through a tied operand: the results are early-clobber outputs, the reads plain inputs.)
+#define SMRF_RED_STEP(OP, x, y, px, py, tx, ty, u, w) OP " %" #x ", %" #px ", %" #tx ", %" #u "\n\t" OP " %" #y ", %" #py ", %" #ty ", %" #w
+template <bool DIL>
+__device__ __forceinline__ void red_chain(float a0, float b0, float& x1, float& y1, float tx1, float ty1, float u1, float w1, float& x2,
+                                          float& y2, float tx2, float ty2, float u2, float w2) {
+  if constexpr (DIL)
+    asm volatile(SMRF_RED_STEP("v_max3_f32", 0, 1, 4, 5, 6, 7, 8, 9) "\n\t" SMRF_RED_STEP("v_max3_f32", 2, 3, 0, 1, 10, 11, 12, 13)
+                 : "=&v"(x1), "=&v"(y1), "=&v"(x2), "=&v"(y2)
+                 : "v"(a0), "v"(b0), "v"(tx1), "v"(ty1), "v"(u1), "v"(w1), "v"(tx2), "v"(ty2), "v"(u2), "v"(w2));
+  else
+    asm volatile(SMRF_RED_STEP("v_min3_f32", 0, 1, 4, 5, 6, 7, 8, 9) "\n\t" SMRF_RED_STEP("v_min3_f32", 2, 3, 0, 1, 10, 11, 12, 13)
+                 : "=&v"(x1), "=&v"(y1), "=&v"(x2), "=&v"(y2)
+                 : "v"(a0), "v"(b0), "v"(tx1), "v"(ty1), "v"(u1), "v"(w1), "v"(tx2), "v"(ty2), "v"(u2), "v"(w2));
+}
+template <bool DIL>
+__device__ __forceinline__ void red_chain(float a0, float b0, float& x1, float& y1, float tx1, float ty1, float u1, float w1, float& x2,
+                                          float& y2, float tx2, float ty2, float u2, float w2, float& x3, float& y3, float tx3, float ty3,
+                                          float u3, float w3) {
+  if constexpr (DIL)
+    asm volatile(SMRF_RED_STEP("v_max3_f32", 0, 1, 6, 7, 8, 9, 10, 11) "\n\t" SMRF_RED_STEP("v_max3_f32", 2, 3, 0, 1, 12, 13, 14, 15) "\n\t"
+                 SMRF_RED_STEP("v_max3_f32", 4, 5, 2, 3, 16, 17, 18, 19)
+                 : "=&v"(x1), "=&v"(y1), "=&v"(x2), "=&v"(y2), "=&v"(x3), "=&v"(y3)
+                 : "v"(a0), "v"(b0), "v"(tx1), "v"(ty1), "v"(u1), "v"(w1), "v"(tx2), "v"(ty2), "v"(u2), "v"(w2), "v"(tx3), "v"(ty3),
+                   "v"(u3), "v"(w3));
+  else
+    asm volatile(SMRF_RED_STEP("v_min3_f32", 0, 1, 6, 7, 8, 9, 10, 11) "\n\t" SMRF_RED_STEP("v_min3_f32", 2, 3, 0, 1, 12, 13, 14, 15) "\n\t"
+                 SMRF_RED_STEP("v_min3_f32", 4, 5, 2, 3, 16, 17, 18, 19)
+                 : "=&v"(x1), "=&v"(y1), "=&v"(x2), "=&v"(y2), "=&v"(x3), "=&v"(y3)
+                 : "v"(a0), "v"(b0), "v"(tx1), "v"(ty1), "v"(u1), "v"(w1), "v"(tx2), "v"(ty2), "v"(u2), "v"(w2), "v"(tx3), "v"(ty3),
+                   "v"(u3), "v"(w3));
+}
+template <bool DIL>
+__device__ __forceinline__ void red_chain(float a0, float b0, float& x1, float& y1, float tx1, float ty1, float u1, float w1, float& x2,
+                                          float& y2, float tx2, float ty2, float u2, float w2, float& x3, float& y3, float tx3, float ty3,
+                                          float u3, float w3, float& x4, float& y4, float tx4, float ty4, float u4, float w4) {
+  if constexpr (DIL)
+    asm volatile(SMRF_RED_STEP("v_max3_f32", 0, 1, 8, 9, 10, 11, 12, 13) "\n\t" SMRF_RED_STEP("v_max3_f32", 2, 3, 0, 1, 14, 15, 16, 17) "\n\t"
+                 SMRF_RED_STEP("v_max3_f32", 4, 5, 2, 3, 18, 19, 20, 21) "\n\t" SMRF_RED_STEP("v_max3_f32", 6, 7, 4, 5, 22, 23, 24, 25)
+                 : "=&v"(x1), "=&v"(y1), "=&v"(x2), "=&v"(y2), "=&v"(x3), "=&v"(y3), "=&v"(x4), "=&v"(y4)
+                 : "v"(a0), "v"(b0), "v"(tx1), "v"(ty1), "v"(u1), "v"(w1), "v"(tx2), "v"(ty2), "v"(u2), "v"(w2), "v"(tx3), "v"(ty3),
+                   "v"(u3), "v"(w3), "v"(tx4), "v"(ty4), "v"(u4), "v"(w4));
+  else
+    asm volatile(SMRF_RED_STEP("v_min3_f32", 0, 1, 8, 9, 10, 11, 12, 13) "\n\t" SMRF_RED_STEP("v_min3_f32", 2, 3, 0, 1, 14, 15, 16, 17) "\n\t"
+                 SMRF_RED_STEP("v_min3_f32", 4, 5, 2, 3, 18, 19, 20, 21) "\n\t" SMRF_RED_STEP("v_min3_f32", 6, 7, 4, 5, 22, 23, 24, 25)
+                 : "=&v"(x1), "=&v"(y1), "=&v"(x2), "=&v"(y2), "=&v"(x3), "=&v"(y3), "=&v"(x4), "=&v"(y4)
+                 : "v"(a0), "v"(b0), "v"(tx1), "v"(ty1), "v"(u1), "v"(w1), "v"(tx2), "v"(ty2), "v"(u2), "v"(w2), "v"(tx3), "v"(ty3),
+                   "v"(u3), "v"(w3), "v"(tx4), "v"(ty4), "v"(u4), "v"(w4));
+}
+
 // One LDS read of a {row A, row B} cell at byte address `addr + OFF`.  Written as asm so that
 // hipcc cannot fuse two of them into ds_read2_b64, which moves half the bytes per LDS cycle of
 // ds_read_b64 on gfx950 (MI355X_MICROARCH: 128 vs 256 B/clk).  The caller owns the wait
@@ -288,9 +357,22 @@ __device__ __forceinline__ void lds_write2(unsigned addr, Vec2<float>::type v) {
 __device__ __forceinline__ void lds_write2(unsigned addr, Vec2<double>::type v) {
   asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
-template <int N>
+// The counted wait.  BI = false: an asm statement, as every round so far.  BI = true (round 5; the consume phase of the
+// instances ring_fuse.inc switches on): the compiler's own s_waitcnt.  hipcc's hazard recognizer gives an asm statement no
+// length: between an asm that writes a register and a later asm that reads it, it counts only the REAL instructions in
+// between, and with none it inserts `s_nop 0` (gfx950's dst_sel forwarding hazard, assumed for any asm) - with the waits as
+// asm, the first min / max after every wait got one.  The builtin is a real instruction the recognizer counts; the
+// waitcnt insertion pass never weakens or drops it, but it MERGES its own vmcnt waits into it, i.e. moves them earlier:
+// the fused openings R = 12..14 measured 2 % slower with builtin waits everywhere, hence the switch per use.
+template <int N, bool BI = false>
 __device__ __forceinline__ void lds_wait() {   // at most N LDS operations still outstanding
-  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N > 15 ? 15 : N) : "memory");   // 4-bit counter field
+  if constexpr (BI) {
+    // s_waitcnt simm16 on gfx9: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14]; vmcnt = 63, expcnt = 7: not waited for
+    __builtin_amdgcn_s_waitcnt(0xC07F | ((N > 15 ? 15 : N) << 8));   // 4-bit counter field
+    asm volatile("" ::: "memory");             // and no LDS access of the compiler's own moves across it
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N > 15 ? 15 : N) : "memory");
+  }
 }
 
 // Geometry of one kernel instance.  Input rows are handled in PAIRS (A = y, B = y+1): the two
@@ -401,6 +483,17 @@ struct RingCfg {
     for (int i = 1; i < D; ++i) n += greads(g + i);
     return n;
   }
+  // lookup group g's window steps as one asm statement (red_chain): fp32, incremental widths, 2..4 widths, one read per side each
+  static constexpr int FUSE_MODE = INC && sizeof(T) == 4 ? SMRF_RING_FUSE_MODE(T, R, INPLACE) : 0;
+  static constexpr bool fused_red(int g) {
+    if (!(FUSE_MODE & 1)) return false;
+    const int n = gsize(g);
+    if (n < 2 || n > 4) return false;
+    for (int k = 1 + g * G; k < 1 + g * G + n; ++k)
+      if (inc_n(k) != 1) return false;
+    return true;
+  }
+  static constexpr bool SLOT_DELAY = (FUSE_MODE & 2) != 0;   // a group's ring slots updated after the NEXT group's window steps
   static constexpr int NEED = NEED_BASE + (D - 2) * 4 * G * E;
   static constexpr int OCC_EST = NEED <= 64 ? 8 : NEED <= 96 ? 5 : NEED <= 128 ? 4 : NEED <= 168 ? 3 : NEED <= 264 ? 2 : 1;
   static constexpr int OCC_REG = INPLACE && SMRF_RING_INPLACE_OCC(T, R) > 0 ? SMRF_RING_INPLACE_OCC(T, R)
@@ -880,6 +973,27 @@ __device__ __forceinline__ void ring_consume(typename Vec2<T>::type* const L, co
       }(std::make_integer_sequence<int, G>{});
     };
     auto reduce = [&]<int GI>(std::integral_constant<int, GI>) {
+      if constexpr (C::fused_red(GI)) {
+        constexpr int k0 = 1 + GI * G, n = C::gsize(GI), b = GI % D;
+        constexpr int i2 = G > 2 ? 2 : 0, i3 = G > 3 ? 3 : 0;
+        float x0, y0, x1, y1;
+        if constexpr (n == 2) {
+          red_chain<DIL>(ra[k0 - 1], rb[k0 - 1], x0, y0, ta[b][0].x, ta[b][0].y, tb[b][0].x, tb[b][0].y, x1, y1, ta[b][1].x, ta[b][1].y,
+                         tb[b][1].x, tb[b][1].y);
+        } else if constexpr (n == 3) {
+          float x2, y2;
+          red_chain<DIL>(ra[k0 - 1], rb[k0 - 1], x0, y0, ta[b][0].x, ta[b][0].y, tb[b][0].x, tb[b][0].y, x1, y1, ta[b][1].x, ta[b][1].y,
+                         tb[b][1].x, tb[b][1].y, x2, y2, ta[b][i2].x, ta[b][i2].y, tb[b][i2].x, tb[b][i2].y);
+          ra[k0 + 2] = x2; rb[k0 + 2] = y2;
+        } else {
+          float x2, y2, x3, y3;
+          red_chain<DIL>(ra[k0 - 1], rb[k0 - 1], x0, y0, ta[b][0].x, ta[b][0].y, tb[b][0].x, tb[b][0].y, x1, y1, ta[b][1].x, ta[b][1].y,
+                         tb[b][1].x, tb[b][1].y, x2, y2, ta[b][i2].x, ta[b][i2].y, tb[b][i2].x, tb[b][i2].y, x3, y3, ta[b][i3].x,
+                         ta[b][i3].y, tb[b][i3].x, tb[b][i3].y);
+          ra[k0 + 2] = x2; rb[k0 + 2] = y2; ra[k0 + 3] = x3; rb[k0 + 3] = y3;
+        }
+        ra[k0] = x0; rb[k0] = y0; ra[k0 + 1] = x1; rb[k0 + 1] = y1;
+      } else
       [&]<int... I>(std::integer_sequence<int, I...>) {
         (([&] {
            constexpr int k = 1 + GI * G + I;
@@ -926,19 +1040,22 @@ __device__ __forceinline__ void ring_consume(typename Vec2<T>::type* const L, co
     rb[0] = own[p].y;
     // the two rows this pair completes (before their slots are overwritten)
     outv[2 * p] = op2<DIL>(acc[0], ra[0]);
+    constexpr bool SD = C::SLOT_DELAY && NG >= 2;          // slots one group late (RingCfg::SLOT_DELAY)
     [&]<int... GI>(std::integer_sequence<int, GI...>) {
       (([&] {
          if constexpr (GI + D - 1 < NG) issue(std::integral_constant<int, GI + D - 1>{});
-         lds_wait<C::inflight_after(GI)>();               // reads of the groups issued after group GI
+         lds_wait<C::inflight_after(GI), (C::FUSE_MODE != 0)>();   // reads of the groups issued after group GI
          reduce(std::integral_constant<int, GI>{});
-         if constexpr (GI == 0) {
+         constexpr int GS = SD ? GI - 1 : GI;             // the group whose slots are updated here
+         if constexpr (GS == 0) {
            if constexpr (R >= 2) outv[2 * p + 1] = op3<DIL>(acc[1], ra[KR1], rb[0]);
          }
-         slots(std::integral_constant<int, GI>{});
+         if constexpr (GS >= 0) slots(std::integral_constant<int, GS>{});
        }()), ...);
     }(std::make_integer_sequence<int, NG>{});
     if constexpr (R == 1) outv[2 * p + 1] = op3<DIL>(acc[1], ra[KR1], rb[0]);
     __builtin_amdgcn_s_setprio(0);
+    if constexpr (SD) slots(std::integral_constant<int, NG - 1>{});
     slots(std::integral_constant<int, NG>{});           // second half, all widths are in registers
     acc[2 * R - 2] = op2<DIL>(ra[0], rb[KR1]);
     acc[2 * R - 1] = rb[0];
@@ -1006,6 +1123,27 @@ __device__ __forceinline__ void ring_consume_inplace(typename Vec2<T>::type* con
       }(std::make_integer_sequence<int, G>{});
     };
     auto reduce = [&]<int GI>(std::integral_constant<int, GI>) {
+      if constexpr (C::fused_red(GI)) {
+        constexpr int k0 = 1 + GI * G, n = C::gsize(GI), b = GI % D;
+        constexpr int i2 = G > 2 ? 2 : 0, i3 = G > 3 ? 3 : 0;
+        float x0, y0, x1, y1;
+        if constexpr (n == 2) {
+          red_chain<DIL>(ra[k0 - 1], rb[k0 - 1], x0, y0, ta[b][0].x, ta[b][0].y, tb[b][0].x, tb[b][0].y, x1, y1, ta[b][1].x, ta[b][1].y,
+                         tb[b][1].x, tb[b][1].y);
+        } else if constexpr (n == 3) {
+          float x2, y2;
+          red_chain<DIL>(ra[k0 - 1], rb[k0 - 1], x0, y0, ta[b][0].x, ta[b][0].y, tb[b][0].x, tb[b][0].y, x1, y1, ta[b][1].x, ta[b][1].y,
+                         tb[b][1].x, tb[b][1].y, x2, y2, ta[b][i2].x, ta[b][i2].y, tb[b][i2].x, tb[b][i2].y);
+          ra[k0 + 2] = x2; rb[k0 + 2] = y2;
+        } else {
+          float x2, y2, x3, y3;
+          red_chain<DIL>(ra[k0 - 1], rb[k0 - 1], x0, y0, ta[b][0].x, ta[b][0].y, tb[b][0].x, tb[b][0].y, x1, y1, ta[b][1].x, ta[b][1].y,
+                         tb[b][1].x, tb[b][1].y, x2, y2, ta[b][i2].x, ta[b][i2].y, tb[b][i2].x, tb[b][i2].y, x3, y3, ta[b][i3].x,
+                         ta[b][i3].y, tb[b][i3].x, tb[b][i3].y);
+          ra[k0 + 2] = x2; rb[k0 + 2] = y2; ra[k0 + 3] = x3; rb[k0 + 3] = y3;
+        }
+        ra[k0] = x0; rb[k0] = y0; ra[k0 + 1] = x1; rb[k0 + 1] = y1;
+      } else
       [&]<int... I>(std::integer_sequence<int, I...>) {
         (([&] {
            constexpr int k = 1 + GI * G + I;
@@ -1056,16 +1194,23 @@ __device__ __forceinline__ void ring_consume_inplace(typename Vec2<T>::type* con
     ra[0] = own[P].x;
     rb[0] = own[P].y;
     outv[2 * P] = op2<DIL>(acc[0], ra[0]);
+    constexpr bool SD = C::SLOT_DELAY && NG >= 2;          // slots one group late (RingCfg::SLOT_DELAY)
     [&]<int... GI>(std::integer_sequence<int, GI...>) {
       (([&] {
          if constexpr (GI + D - 1 < NG) issue(std::integral_constant<int, GI + D - 1>{});
-         lds_wait<C::inflight_after(GI)>();
+         lds_wait<C::inflight_after(GI), (C::FUSE_MODE != 0)>();
          reduce(std::integral_constant<int, GI>{});
-         if constexpr (GI == (KR1 - 1) / G) outv[2 * P + 1] = op3<DIL>(acc[1], ra[KR1], rb[0]);   // before F[1] is overwritten
-         if constexpr (GI == NG - 1) __builtin_amdgcn_s_setprio(0);
-         slots(std::integral_constant<int, GI>{});
+         constexpr int GS = SD ? GI - 1 : GI;             // the group whose slots are updated here
+         if constexpr (GS == (KR1 - 1) / G) outv[2 * P + 1] = op3<DIL>(acc[1], ra[KR1], rb[0]);   // before F[1] is overwritten
+         if constexpr (!SD && GI == NG - 1) __builtin_amdgcn_s_setprio(0);
+         if constexpr (GS >= 0) slots(std::integral_constant<int, GS>{});
        }()), ...);
     }(std::make_integer_sequence<int, NG>{});
+    if constexpr (SD) {
+      __builtin_amdgcn_s_setprio(0);
+      if constexpr (NG - 1 == (KR1 - 1) / G) outv[2 * P + 1] = op3<DIL>(acc[1], ra[KR1], rb[0]);
+      slots(std::integral_constant<int, NG - 1>{});
+    }
     // the pair's two new-born slots (logical R-1, R of the next pair's mapping) take the registers of B[0], B[1]
     acc[R - 1 + (2 * P) % M] = op2<DIL>(ra[0], rb[KR1]);
     acc[R - 1 + (1 + 2 * P) % M] = rb[0];

@@ -23,6 +23,11 @@
 // HBM-bound: per iteration about 3 plane reads + 2 plane writes of each of u (2 planes), v, w, x.
 #include "lsqr_core.h"
 
+// the single-device solver's iteration with the x / w / dk steps riding in the v pass (atuxw_kernel): 0 = round 4's form
+#ifndef SMRF_SPRINGS_SPLIT
+#define SMRF_SPRINGS_SPLIT 1
+#endif
+
 namespace {
 
 // One row band of the raster.  Plane pointers address the first OWN row; row -1 and row `rows` are
@@ -340,9 +345,193 @@ __global__ __launch_bounds__(256) void xwav_kernel(const Band b) {
   if (threadIdx.x == 0) { b.part[SMRF_TILE_SLOT(tl)] = td; b.part[MAXB + SMRF_TILE_SLOT(tl)] = tu; }
 }
 
-__global__ __launch_bounds__(256) void scatter_kernel(double* __restrict__ A, const Band b) {
+// ---- single-device solver, round 5: the x / w / dk steps ride in the pass that makes v ----------------------------
+// Iteration k was [atu: v_k, |v|^2] [alfa, rotation] [xwav: x_k, w_k, |dk|^2; u_{k+1}, |u|^2] [tests; beta]: 13 plane
+// touches (atu 3 reads + 1 write, xwav 5 + 4).  The rotation's rho, phi - hence t1 = phi / rho and 1 / rho - need only
+// rhobar and beta (lsqr_core.h: rho_step), so they exist BEFORE the v pass, and that pass reads v_{k-1} and can read w_{k-2}:
+//   atuxw (iteration k):  w_{k-1} = v_{k-1} / alfa_{k-1} + t2_{k-1} w_{k-2}   (k = 1: w_0 = v_0 / alfa_0 - no w_init pass)
+//                         dk_k = w_{k-1} / rho_k, |dk|^2;   v_k = S^T u_k - beta_k v_{k-1}, |v|^2
+//                         k even: x_k = (x_{k-2} + t1_{k-1} w_{k-2}) + t1_k w_{k-1}  - both steps, from registers
+//   [alfa_k, rest of the rotation, tests_k]      av2: u_{k+1} = S v_k - alfa_k u_k, |u|^2      [beta_{k+1}, rho_step]
+// x is read and written every SECOND iteration only: 12 touches instead of 13 (99 instead of 106 B per cell and iteration
+// with the hole bytes), no separate w_init pass, w never initialised by the set-up.  A solve that stops at an odd k leaves
+// x one step behind; scatter_kernel adds t1_k w_{k-1} (w still holds it: av2 and the next atuxw return at once).
+// Every vector entry goes through the same operations on the same operands in the same order as before (x_k's two
+// roundings, w, dk, v), every partial sum runs over the same cells in the same order into the same slot: x, istop and
+// itn are bit-identical to the four-launch form (tools/lsqr_ab.py --equal; the goldens' istop / itn).
+__global__ __launch_bounds__(256) void atuxw_kernel(const Band b) {
+  __shared__ double red[4];
+  __shared__ double red2[4];
+  const Sc* sc = b.sc;
+  if (stopped(sc)) return;
+  const int rows = b.rows, cols = b.cols;
+  const long long ld = b.ld;
+  const LsqrTile tl = lsqr_tile(b.nxcd);
+  const long long itn = sc->itn;                           // k - 1
+  const bool first = itn == 0, xupd = (itn & 1) != 0, bpos = sc->beta_pos != 0;
+  const double ib = sc->inv_beta, ia = sc->inv_alfa, beta = sc->beta;
+  const double t1 = sc->t1, t1p = sc->t1_prev, t2 = sc->t2, ir = sc->inv_rho;
+  double s = 0.0, sd = 0.0;
+  {
+    const int c = tl.x * 256 + (int)threadIdx.x;
+    if (c < cols) {
+      int r = tl.y;
+      uint8_t h = r < rows ? b.hole[(long long)r * ld + c] : (uint8_t)0;
+      for (; r < rows; r += gridDim.y) {
+        const long long i = (long long)r * ld + c;
+        const int rn = r + (int)gridDim.y;
+        const uint8_t hn = rn < rows ? b.hole[(long long)rn * ld + c] : (uint8_t)0;   // one row of the walk ahead (atu_kernel)
+        if (h) {
+          const double vs = ia * b.v[i];
+          double wn;
+          if (first) {
+            wn = vs;                                       // w_0 = v_0 / alfa_0 (lsqr.py:379)
+          } else {
+            const double wo = b.w[i];
+            wn = vs + t2 * wo;                             // w_{k-1} (lsqr.py:461, of the iteration before)
+            if (xupd) b.x[i] = (b.x[i] + t1p * wo) + t1 * wn;   // x_{k-1} then x_k (lsqr.py:460), two roundings as before
+          }
+          b.w[i] = wn;
+          const double dk = ir * wn;                       // lsqr.py:459
+          sd += dk * dk;
+          if (bpos) {                                      // beta == 0: v and alfa stay (lsqr.py:434-441)
+            double y = 0.0;
+            if (r > 0 || b.has_above) y = y - ib * b.uv[i - ld];
+            if (c > 0) y = y - ib * b.uh[i - 1];
+            if (c + 1 < cols) y = y + ib * b.uh[i];
+            if (r + 1 < rows || b.has_below) y = y + ib * b.uv[i];
+            const double nv = y - beta * vs;
+            b.v[i] = nv;
+            s += nv * nv;
+          }
+        }
+        h = hn;
+      }
+    }
+  }
+  const double t = block_sum(s, red);
+  const double td = block_sum(sd, red2);
+  if (threadIdx.x == 0) { b.part[SMRF_TILE_SLOT(tl)] = t; b.part[MAXB + SMRF_TILE_SLOT(tl)] = td; }
+}
+
+// u = S v_s - alfa u_s, partial |u|^2: the u half of xwav_kernel (same walk, same hole-byte prefetch)
+__global__ __launch_bounds__(256) void av2_kernel(const Band b) {
+  __shared__ double red[4];
+  const Sc* sc = b.sc;
+  if (stopped(sc)) return;
+  const double ia = sc->inv_alfa, ib = sc->inv_beta, alfa = sc->alfa;
+  const int rows = b.rows, cols = b.cols;
+  const long long ld = b.ld;
+  double su = 0.0;
+  const LsqrTile tl = lsqr_tile(b.nxcd);
+  {
+    const int c = tl.x * 256 + (int)threadIdx.x;
+    if (c < cols) {
+      const bool has_r = c + 1 < cols;
+      int r = tl.y;
+      uint8_t h0 = 0, h1 = 0, hd = 0;
+      if (r < rows) {
+        const long long i0 = (long long)r * ld + c;
+        h0 = b.hole[i0];
+        if (has_r) h1 = b.hole[i0 + 1];
+        if (r + 1 < rows) hd = b.hole[i0 + ld];
+      }
+      for (; r < rows; r += gridDim.y) {
+        const long long i = (long long)r * ld + c;
+        const int rn = r + (int)gridDim.y;
+        uint8_t n0 = 0, n1 = 0, nd = 0;
+        if (rn < rows) {
+          const long long in = (long long)rn * ld + c;
+          n0 = b.hole[in];
+          if (has_r) n1 = b.hole[in + 1];
+          if (rn + 1 < rows) nd = b.hole[in + ld];
+        }
+        const double v0 = ia * b.v[i];                   // unconditional on purpose (see av_kernel)
+        if (has_r) {
+          if (h0 | h1) {
+            const double nu = (v0 - ia * b.v[i + 1]) - alfa * (ib * b.uh[i]);
+            b.uh[i] = nu;
+            su += nu * nu;
+          }
+        }
+        if (r + 1 < rows) {
+          if (h0 | hd) {
+            const double nu = (v0 - ia * b.v[i + ld]) - alfa * (ib * b.uv[i]);
+            b.uv[i] = nu;
+            su += nu * nu;
+          }
+        }
+        h0 = n0; h1 = n1; hd = nd;
+      }
+    }
+  }
+  const double tu = block_sum(su, red);
+  if (threadIdx.x == 0) b.part[SMRF_TILE_SLOT(tl)] = tu;
+}
+
+// set-up of the single-device solver in ONE plane pass: hole mask (from A itself: the neighbours' NaN-ness is read off the
+// raster, not off a mask written by an earlier launch), right-hand side, v = 0, x = 0 at the holes; partial hole count and
+// partial |b|^2 - mask_kernel + rhs_kernel's cells in rhs_kernel's order (the same |b|^2 bits), without their second read
+// of the raster and without w (atuxw_kernel's first pass writes it)
+__global__ __launch_bounds__(256) void setup_kernel(const double* __restrict__ A, const Band b) {
+  __shared__ double red[4];
+  __shared__ double red2[4];
+  const int rows = b.rows, cols = b.cols;
+  const long long ld = b.ld;
+  double s = 0.0, nh = 0.0;
+  SMRF_FOR_CELLS_P(rows, cols, ld) {
+    const long long ia = (long long)r * cols + c;
+    const double a0 = A[ia];
+    const bool h0 = a0 != a0;
+    const double k0 = h0 ? 0.0 : a0;
+    double eh = 0.0, ev = 0.0;
+    if (c + 1 < cols) {
+      const double a1 = A[ia + 1];
+      const bool h1 = a1 != a1;
+      if (h0 | h1) eh = (h1 ? 0.0 : a1) - k0;
+    }
+    if (r + 1 < rows) {
+      const double a1 = A[ia + cols];
+      const bool h1 = a1 != a1;
+      if (h0 | h1) ev = (h1 ? 0.0 : a1) - k0;
+    }
+    b.hole[i] = h0;
+    b.uh[i] = eh;
+    b.uv[i] = ev;
+    b.v[i] = 0.0;
+    if (h0) b.x[i] = 0.0;
+    nh += h0 ? 1.0 : 0.0;
+    s += eh * eh;
+    s += ev * ev;
+  }
+  const double t = block_sum(s, red);
+  const double tn = block_sum(nh, red2);
+  if (threadIdx.x == 0) {
+    b.part[blockIdx.y * gridDim.x + blockIdx.x] = tn;
+    b.part[MAXB + blockIdx.y * gridDim.x + blockIdx.x] = t;
+  }
+}
+
+__global__ void s_count_bnorm(const Band b) {             // red[0] = holes, red[1] = |b|^2: s_count then s_bnorm
+  Sc* sc = b.sc;
+  sc->nunk = (long long)b.red[0];
+  if (sc->iter_lim < 0) sc->iter_lim = 2 * sc->nunk;
+  if (sc->nunk == 0) sc->done = 1;
+  const double bn = sqrt(b.red[1]);
+  sc->bnorm = bn;
+  sc->beta = bn;
+  sc->beta_pos = bn > 0;
+  sc->inv_beta = bn > 0 ? 1 / bn : 1.0;
+  sc->alfa = 0.0;
+  sc->inv_alfa = 1.0;
+}
+
+// PEND: the solve stopped at an odd iteration k - x still lacks t1_k w_{k-1} (atuxw_kernel)
+__global__ __launch_bounds__(256) void scatter_kernel(double* __restrict__ A, const Band b, int split) {
+  const bool pend = split && (b.sc->itn & 1) != 0;
+  const double t1 = b.sc->t1;
   SMRF_FOR_CELLS_P(b.rows, b.cols, b.ld)
-    if (b.hole[i]) A[(long long)r * b.cols + c] = b.x[i];
+    if (b.hole[i]) A[(long long)r * b.cols + c] = pend ? b.x[i] + t1 * b.w[i] : b.x[i];
 }
 
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -446,7 +635,7 @@ int run_phase(int phase, double* A, const Band& b, hipStream_t st) {
     case PH_ALFA_ROT: hipLaunchKernelGGL(s_alfa_rot, dim3(1), dim3(1), 0, st, b); break;
     case PH_XW: hipLaunchKernelGGL(xw_kernel, g2, dim3(256), 0, st, b); break;   // its sum rode with PH_ATU's
     case PH_TESTS: hipLaunchKernelGGL(s_tests, dim3(1), dim3(1), 0, st, b); break;
-    case PH_SCATTER: hipLaunchKernelGGL(scatter_kernel, g2, dim3(256), 0, st, A, b); break;
+    case PH_SCATTER: hipLaunchKernelGGL(scatter_kernel, g2, dim3(256), 0, st, A, b, 0); break;
     default: return smrf_fail(SMRF_E_ARG, "unknown springs phase %d", phase);
   }
   SMRF_LAUNCH_CHECK();
@@ -478,28 +667,52 @@ int smrf_springs_lsqr_f64(double* d_A, int rows, int cols, double atol, double b
     return smrf_fail(SMRF_E_WORKSPACE, "springs workspace too small");
   const Band b = band_of(d_workspace, rows, cols, padded_pitch(cols), 0, 0);
   if (int rc = init_scalars(b, atol, btol, conlim, iter_lim, stream)) return rc;
+  const dim3 g2 = grid2d(b);
+  const int nb = (int)(g2.x * g2.y);
+#if SMRF_SPRINGS_SPLIT
+  // set-up: one plane pass (mask + right-hand side + counts), the first v = S^T u, alfa; then u_1 and beta_1 + rho_step
+  hipLaunchKernelGGL(setup_kernel, g2, dim3(256), 0, stream, (const double*)d_A, b);
+  hipLaunchKernelGGL(reduce2_kernel, dim3(1), dim3(256), 0, stream, (const double*)b.part, nb, b.red);
+  hipLaunchKernelGGL(s_count_bnorm, dim3(1), dim3(1), 0, stream, b);
+  hipLaunchKernelGGL(atu_kernel<false>, g2, dim3(256), 0, stream, b);
+  hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(256), 0, stream, (const double*)b.part, nb, b.red);
+  hipLaunchKernelGGL(s_init_alfa, dim3(1), dim3(1), 0, stream, b);
+  SMRF_LAUNCH_CHECK();
+#else
   for (int ph : {PH_MASK, PH_RHS, PH_BNORM, PH_ATU, PH_INIT_ALFA})
     if (int rc = run_phase(ph, d_A, b, stream)) return rc;
+#endif
   Sc out{};
   SMRF_HIP_CHECK(hipMemcpyAsync(&out, b.sc, sizeof(out), hipMemcpyDeviceToHost, stream));
   SMRF_HIP_CHECK(hipStreamSynchronize(stream));
   const long long lim = out.iter_lim;
-  const dim3 g2 = grid2d(b);
-  const int nb = (int)(g2.x * g2.y);
-  // Iteration i = [u = S v - alfa u; beta] [v = S^T u - beta v; alfa, rotation] [x, w update; tests].
-  // Four launches per iteration: atu | reduce+alfa_rot | xw(i) fused with av(i+1) | reduce+tests(i)+beta(i+1).
   if (!out.done && out.istop == 0 && out.itn < lim) {
+#if SMRF_SPRINGS_SPLIT
+    hipLaunchKernelGGL(av2_kernel, g2, dim3(256), 0, stream, b);
+    hipLaunchKernelGGL((reduce_scalar_kernel<4, Band>), dim3(1), dim3(256), 0, stream, b, nb);
+#else
     hipLaunchKernelGGL(av_kernel, g2, dim3(256), 0, stream, b);
     hipLaunchKernelGGL((reduce_scalar_kernel<0, Band>), dim3(1), dim3(256), 0, stream, b, nb);
+#endif
     SMRF_LAUNCH_CHECK();
   }
   int chunk = 4;
   while (!out.done && out.istop == 0 && out.itn < lim) {
     for (int k = 0; k < chunk; ++k) {
+#if SMRF_SPRINGS_SPLIT
+      // Iteration k = [w_{k-1}, dk_k, (x), v_k] [alfa_k, rotation, tests_k] [u_{k+1}] [beta_{k+1}, rho_{k+1}]  (atuxw_kernel)
+      hipLaunchKernelGGL(atuxw_kernel, g2, dim3(256), 0, stream, b);
+      hipLaunchKernelGGL((reduce_scalar_kernel<3, Band>), dim3(1), dim3(256), 0, stream, b, nb);
+      hipLaunchKernelGGL(av2_kernel, g2, dim3(256), 0, stream, b);
+      hipLaunchKernelGGL((reduce_scalar_kernel<4, Band>), dim3(1), dim3(256), 0, stream, b, nb);
+#else
+      // Iteration i = [u = S v - alfa u; beta] [v = S^T u - beta v; alfa, rotation] [x, w update; tests].
+      // Four launches per iteration: atu | reduce+alfa_rot | xw(i) fused with av(i+1) | reduce+tests(i)+beta(i+1).
       hipLaunchKernelGGL(atu_kernel<false>, g2, dim3(256), 0, stream, b);
       hipLaunchKernelGGL((reduce_scalar_kernel<1, Band>), dim3(1), dim3(256), 0, stream, b, nb);
       hipLaunchKernelGGL(xwav_kernel, g2, dim3(256), 0, stream, b);
       hipLaunchKernelGGL((reduce_scalar_kernel<2, Band>), dim3(1), dim3(256), 0, stream, b, nb);
+#endif
     }
     SMRF_LAUNCH_CHECK();
     SMRF_HIP_CHECK(hipMemcpyAsync(&out, b.sc, sizeof(out), hipMemcpyDeviceToHost, stream));
@@ -507,7 +720,8 @@ int smrf_springs_lsqr_f64(double* d_A, int rows, int cols, double atol, double b
     chunk = std::min(32, chunk * 2);
   }
   if (out.nunk > 0) {
-    if (int rc = run_phase(PH_SCATTER, d_A, b, stream)) return rc;
+    hipLaunchKernelGGL(scatter_kernel, g2, dim3(256), 0, stream, d_A, b, SMRF_SPRINGS_SPLIT);
+    SMRF_LAUNCH_CHECK();
     SMRF_HIP_CHECK(hipStreamSynchronize(stream));
   }
   *h_istop = out.istop;

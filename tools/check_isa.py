@@ -82,15 +82,18 @@ def lds_hazards(text):
     return bad
 
 
+DEFS = []
+
+
 def one(job):
     part, f64, tmp = job
     if part < 0:                                           # the chained / table-free launches (both dtypes in one unit)
         out = os.path.join(tmp, "chain.s")
-        cmd = [hipcc()] + [f for f in FLAGS if f != "-fPIC"] + ["--offload-device-only", "-S", os.path.join(CSRC, "chain.hip"),
+        cmd = [hipcc()] + [f for f in FLAGS if f != "-fPIC"] + DEFS + ["--offload-device-only", "-S", os.path.join(CSRC, "chain.hip"),
                                                                "-o", out]
     else:
         out = os.path.join(tmp, "ring_%d_%d.s" % (f64, part))
-        cmd = [hipcc()] + [f for f in FLAGS if f != "-fPIC"] + ["-DPART=%d" % part, "-DSMRF_F64=%d" % f64, "--offload-device-only",
+        cmd = [hipcc()] + [f for f in FLAGS if f != "-fPIC"] + DEFS + ["-DPART=%d" % part, "-DSMRF_F64=%d" % f64, "--offload-device-only",
                                                                "-S", os.path.join(CSRC, "ring_part.hip"), "-o", out]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
@@ -117,9 +120,12 @@ def one(job):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("-j", type=int, default=min(8, os.cpu_count() or 1))
+    ap.add_argument("--defs", default="", help="extra compiler flags (variant builds), space separated")
+    ap.add_argument("--f32-only", action="store_true")
     a = ap.parse_args()
+    DEFS[:] = [d for d in a.defs.split() if d]
     with tempfile.TemporaryDirectory() as tmp:
-        jobs = [(p, f, tmp) for f in (0, 1) for p in range(RING_PARTS)] + [(-1, 0, tmp)]
+        jobs = [(p, f, tmp) for f in ((0,) if a.f32_only else (0, 1)) for p in range(RING_PARTS)] + [(-1, 0, tmp)]
         with ThreadPoolExecutor(max_workers=a.j) as ex:
             res = list(ex.map(one, jobs))
     n = 0

@@ -31,6 +31,26 @@ void* get() { return (void*)ring_kernel<float, RR, DILL, 256, kNP>; }
 """
 
 KINDS = ["minmax", "mov", "valu_other", "ds_read", "ds_write", "vmem", "salu", "wait", "barrier", "branch"]
+# round 5: the scalar side by category
+SCALAR = ["s_nop", "s_waitcnt", "s_setprio", "salu_addr", "salu_cond", "branch", "barrier"]
+
+
+def scalar_kind(op):
+    if op == "s_nop":
+        return "s_nop"
+    if op == "s_waitcnt":
+        return "s_waitcnt"
+    if op == "s_setprio":
+        return "s_setprio"
+    if op == "s_barrier":
+        return "barrier"
+    if op.startswith(("s_cbranch", "s_branch")):
+        return "branch"
+    if op.startswith(("s_cmp", "s_cselect", "s_and", "s_or", "s_andn2", "s_xor", "s_not", "s_mov_b64")) or "saveexec" in op:
+        return "salu_cond"          # uniform tests, exec masks
+    if op.startswith("s_"):
+        return "salu_addr"          # row offsets, 64-bit address arithmetic, loop counters
+    return None
 
 
 def kind_of(op):
@@ -119,6 +139,9 @@ def analyse(text, dil):
         ph = "epilogue" if phase.startswith("epilogue") else phase
         counts.setdefault(ph, {}).setdefault(kind_of(op), 0)
         counts[ph][kind_of(op)] += 1
+        sk = scalar_kind(op)
+        if sk:
+            counts[ph]["sc:" + sk] = counts[ph].get("sc:" + sk, 0) + 1
     info["loop_lines"] = hi - lo
     return info, counts
 
@@ -150,6 +173,15 @@ def main():
             for ph in sorted(counts):
                 out.append("| %s | " % ph + " | ".join("%.1f" % (counts[ph].get(k, 0) / rows) for k in KINDS) + " |")
             out.append("| **all, per 64-cell row** | " + " | ".join("**%.1f**" % (tot[k] / rows) for k in KINDS) + " |")
+            out.append("")
+            out.append("scalar side per 64-cell row | " + " | ".join(SCALAR) + " | sum")
+            out.append("---|" + "---|" * (len(SCALAR) + 1))
+            for ph in sorted(counts):
+                v = [counts[ph].get("sc:" + k, 0) / rows for k in SCALAR]
+                if sum(v):
+                    out.append("%s | " % ph + " | ".join("%.1f" % x for x in v) + " | %.1f" % sum(v))
+            sv = [sum(c.get("sc:" + k, 0) for c in counts.values()) / rows for k in SCALAR]
+            out.append("**all** | " + " | ".join("**%.1f**" % x for x in sv) + " | **%.1f**" % sum(sv))
             out.append("")
             out.append("VALU per row %.1f (min / max %.1f, v_mov %.1f, other %.1f) against R + K = %d (R - 1 = %d ring updates, K - 1 = %d "
                        "window steps, 2 for the completed rows): %.1f over; LDS reads per row %.1f" %

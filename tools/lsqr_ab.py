@@ -66,9 +66,16 @@ for i in range(a.reps + 1):
         if i:
             res.setdefault(name, []).append(e0.elapsed_time(e1))
         res[name + "_info"] = (istop.value, itn.value, nunk.value, float(A.sum().item()))
+        if name == "cur" and "ref" not in res:
+            res["ref"] = A.clone()
+        elif "ref" in res:
+            res[name + "_equal"] = bool(torch.equal(A, res["ref"]))
+            res[name + "_maxdiff"] = float((A - res["ref"]).abs().max().item())
         del ws, A
 for name in fns:
     t = float(np.median(res[name]))
     istop, itn, nunk, s = res[name + "_info"]
     print("%-12s %.1f ms  istop %d itn %d  %.3f ms/iter  %.0f GB/s at 106 B/cell/iter  sum %.6f" %
-          (name, t, istop, itn, t / max(itn, 1), n * n * 106.0 * itn / t / 1e6, s), flush=True)
+          (name, t, istop, itn, t / max(itn, 1), n * n * 106.0 * itn / t / 1e6, s) +
+          ("" if name + "_equal" not in res else "  bit-equal to cur: %s (max |diff| %.3g)" % (res[name + "_equal"], res[name + "_maxdiff"])),
+          flush=True)
