@@ -59,3 +59,99 @@ def test_bench_bare_multi_gpu_refuses_without_devices():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                        timeout=900, env=env2)
     assert r.returncode == 4 and "started 3 ranks" in r.stderr
+
+
+def test_split_rotation_equals_alfa_rot_step():
+    """csrc/lsqr_core.h: round 5's single-device spring solver cuts alfa_rot_step in two - rho_step right after beta (the
+    plane rotation needs only rhobar and beta) and alfa_rest_step after |v|^2 - so that t1 and 1 / rho exist one vector pass
+    early.  Replayed here in Python floats (IEEE doubles, same operations in the same order): every scalar of both forms is
+    bit-identical over a long random recurrence, including the b == 0 / a == 0 / |b| > |a| branches of sym_ortho."""
+    import math
+    import random
+
+    def sgn(a):
+        return 1.0 if a > 0 else (-1.0 if a < 0 else 0.0)
+
+    def sym_ortho(a, b):
+        if b == 0:
+            return sgn(a), 0.0, abs(a)
+        if a == 0:
+            return 0.0, sgn(b), abs(b)
+        if abs(b) > abs(a):
+            tau = a / b
+            sn = sgn(b) / math.sqrt(1 + tau * tau)
+            cs = sn * tau
+            return cs, sn, b / sn
+        tau = b / a
+        cs = sgn(a) / math.sqrt(1 + tau * tau)
+        sn = cs * tau
+        return cs, sn, a / cs
+
+    def beta_step(s, sum_u):
+        bt = math.sqrt(sum_u)
+        s["beta"], s["beta_pos"] = bt, bt > 0
+        if bt > 0:
+            s["inv_beta"] = 1 / bt
+            s["anorm"] = math.sqrt(s["anorm"] * s["anorm"] + s["alfa"] * s["alfa"] + bt * bt)
+        else:
+            s["inv_beta"] = 1.0
+
+    def rest(s, cs, sn, rho, phi, theta):                 # the norm(x) estimate, lsqr.py:474-483
+        delta = s["sn2"] * rho
+        gambar = -s["cs2"] * rho
+        rhs = phi - delta * s["z"]
+        zbar = rhs / gambar
+        s["xnorm"] = math.sqrt(s["xxnorm"] + zbar * zbar)
+        gamma = math.sqrt(gambar * gambar + theta * theta)
+        s["cs2"], s["sn2"], s["z"] = gambar / gamma, theta / gamma, rhs / gamma
+        s["xxnorm"] = s["xxnorm"] + s["z"] * s["z"]
+
+    def alfa_rot_step(s, sum_v):                          # round 4: everything after |v|^2
+        if s["beta_pos"]:
+            a = math.sqrt(sum_v)
+            s["alfa"], s["inv_alfa"] = a, (1 / a if a > 0 else 1.0)
+        cs, sn, rho = sym_ortho(s["rhobar"], s["beta"])
+        theta = sn * s["alfa"]
+        s["rhobar"] = -cs * s["alfa"]
+        phi = cs * s["phibar"]
+        s["phibar"] = sn * s["phibar"]
+        s["tau"] = sn * phi
+        s["t1"], s["t2"], s["inv_rho"] = phi / rho, -theta / rho, 1 / rho
+        rest(s, cs, sn, rho, phi, theta)
+
+    def rho_step(s):                                      # round 5, right after beta_step
+        cs, sn, rho = sym_ortho(s["rhobar"], s["beta"])
+        s["cs"], s["sn"], s["rho"] = cs, sn, rho
+        s["phi"] = cs * s["phibar"]
+        s["t1"], s["inv_rho"] = s["phi"] / rho, 1 / rho
+
+    def alfa_rest_step(s, sum_v):                         # round 5, after |v|^2
+        if s["beta_pos"]:
+            a = math.sqrt(sum_v)
+            s["alfa"], s["inv_alfa"] = a, (1 / a if a > 0 else 1.0)
+        cs, sn, rho, phi = s["cs"], s["sn"], s["rho"], s["phi"]
+        theta = sn * s["alfa"]
+        s["rhobar"] = -cs * s["alfa"]
+        s["phibar"] = sn * s["phibar"]
+        s["tau"] = sn * phi
+        s["t2"] = -theta / rho
+        rest(s, cs, sn, rho, phi, theta)
+
+    rng = random.Random(5)
+    init = dict(alfa=0.7, beta=1.3, inv_alfa=1 / 0.7, inv_beta=1 / 1.3, rhobar=0.7, phibar=1.3, anorm=0.0, xxnorm=0.0, z=0.0,
+                cs2=-1.0, sn2=0.0, t1=0.0, t2=0.0, inv_rho=0.0, xnorm=0.0, tau=0.0, beta_pos=True)
+    a, b = dict(init), dict(init)
+    keys = ["alfa", "beta", "rhobar", "phibar", "anorm", "xxnorm", "z", "cs2", "sn2", "t1", "t2", "inv_rho", "xnorm", "tau"]
+    for it in range(400):
+        su = 0.0 if it == 137 else rng.uniform(1e-6, 10.0) ** 2      # one beta == 0 step (sym_ortho's b == 0 branch)
+        sv = rng.uniform(1e-6, 10.0) ** 2
+        if it == 211:
+            a["rhobar"] = b["rhobar"] = 0.0                           # the a == 0 branch
+        beta_step(a, su)
+        alfa_rot_step(a, sv)
+        beta_step(b, su)
+        rho_step(b)
+        t1_early, ir_early = b["t1"], b["inv_rho"]                    # what atuxw_kernel reads before alfa exists
+        alfa_rest_step(b, sv)
+        assert (t1_early, ir_early) == (a["t1"], a["inv_rho"]), it
+        assert all(a[k] == b[k] or (a[k] != a[k] and b[k] != b[k]) for k in keys), (it, [(k, a[k], b[k]) for k in keys if a[k] != b[k]])

@@ -18,7 +18,7 @@ import sys
 
 
 def short(name):
-    for k in ("mask_kernel", "rhs_kernel", "setup_kernel", "atu_kernel", "xwav_kernel", "av_kernel", "w_init_kernel", "scatter_kernel",
+    for k in ("atuxw_kernel", "av2_kernel", "s_count_bnorm", "mask_kernel", "rhs_kernel", "setup_kernel", "atu_kernel", "xwav_kernel", "av_kernel", "w_init_kernel", "scatter_kernel",
               "reduce_scalar_kernel", "reduce2_kernel", "reduce_kernel", "s_count", "s_bnorm", "s_init_alfa", "xw_kernel",
               "__amd_rocclr_copyBuffer"):
         if k in name:
@@ -39,7 +39,11 @@ def main():
     assert all(k[2] for k in ks), [k[3][:60] for k in ks if not k[2]]
     span = ks[-1][1] - ks[0][0]
     # iterations: an atu_kernel after the set-up's own (the first one) starts iteration i; durations tell real from stopped
-    atu = [i for i, k in enumerate(ks) if k[2] == "atu_kernel"]
+    split = any(k[2] == "atuxw_kernel" for k in ks)      # round 5's iteration: atuxw | reduce | av2 | reduce
+    if split:
+        atu = [next(i for i, k in enumerate(ks) if k[2] == "atu_kernel")] + [i for i, k in enumerate(ks) if k[2] == "atuxw_kernel"]
+    else:
+        atu = [i for i, k in enumerate(ks) if k[2] == "atu_kernel"]
     durs = sorted(ks[i][1] - ks[i][0] for i in atu[1:])
     typical = durs[len(durs) // 2]
     real_iters = [i for i in atu[1:] if ks[i][1] - ks[i][0] > 0.2 * typical]
@@ -66,8 +70,8 @@ def main():
         elif i >= end_real:
             add("launches past the stop", d + gap)
         else:
-            if k[2] in ("atu_kernel", "xwav_kernel"):
-                add("streaming kernels (atu + xwav), real iterations", d)
+            if k[2] in ("atu_kernel", "xwav_kernel", "atuxw_kernel", "av2_kernel"):
+                add("streaming kernels (atu + xwav | atuxw + av2), real iterations", d)
             elif k[2] == "__amd_rocclr_copyBuffer":
                 add("polls (gap > 20 us before a kernel: host readback + re-enqueue)", d)
             else:

@@ -7,7 +7,7 @@
 # the fp64 progressive_filter, the compute-only time of a 1/8 band, the misc op-rate micro-benchmark.
 # Under rocprofv3 the program after "--" is always python3 / a binary itself (no env, no bash -c).
 set -e
-tag=${1:-r04}
+tag=${1:-r05}
 out=$(pwd)/gpurun_out/$tag
 R=$(pwd)
 mkdir -p $out
@@ -26,6 +26,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_smrf100 -- py
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_f64 -- python3 $R/tools/window_ab.py --shapes 8192x8192 --windows 50 --dtype f64 --fused 0 --reps 3 > $out/f64_windows.log 2> $out/f64.err < /dev/null
 cd $R
 python tools/band_compute.py --reps 5 > $out/band_compute.log 2>&1 < /dev/null
+for w in 2 4; do python tools/band_compute.py --world $w --rank $((w/2)) --reps 4 2>&1 | grep -E "budget (0|None), overlap False" >> $out/band_compute.log; done
 # the micro-benchmarks are built from their sources here (no binary is tracked: ADVICE r4)
 for u in misc_rate stream_rate; do
   hipcc --offload-arch=gfx950 -O3 tools/ubench/$u.hip -o tools/ubench/$u
@@ -37,4 +38,6 @@ bash tools/pmc_lsqr.sh $out/pmc_lsqr > $out/pmc_lsqr.log 2>&1
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_lsqr -- python3 $R/tools/pmc_lsqr_run.py > $out/lsqr_trace.log 2> $out/lsqr_trace.err < /dev/null
 cd $R
+# round 5: where the time of one solve goes (timestamps of the trace above)
+python tools/lsqr_attribution.py $(find $out/trace_lsqr -name "*kernel_trace.csv" | head -1) $out/lsqr_attribution.md > /dev/null
 find $out -name "*kernel_stats.csv" | head

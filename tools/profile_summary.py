@@ -115,7 +115,7 @@ def _windows(hot):
     return agg.items()
 
 
-ROUND = 4
+ROUND = 5
 
 
 def pmc(fetch_csv, write_csv, n, windows, out):

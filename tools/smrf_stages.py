@@ -5,10 +5,11 @@
 
 ``run()`` is also what bench.py's ``secondary`` block calls.  Stages are timed one by one (synchronise, wall clock)
 on device-resident points, then the public ``neilpy_amd.smrf`` call is timed as a whole on the same tensors.
-LSQR figures: ``ms_per_iteration`` and ``gbps`` = 106 B x raster cells / that time - the bytes one iteration of the
-matrix-free solver moves over its planes (u two planes, v, w, x float64 read + written where a hole is, plus the hole
-bytes; the hardware counters read 106.9 B on a raster with 74 % holes, profiles/r04_lsqr_traffic.md) - an
-upper bound on rasters with few holes.
+LSQR figures: ``ms_per_iteration`` and ``gbps`` = 99 B x raster cells / that time - the bytes one iteration of the
+matrix-free solver moves over its planes since round 5 (u two planes read + written and read again, v read twice and
+written, w read + written, x read + written every second iteration, plus the hole bytes: DESIGN 4.3,
+profiles/r05_lsqr_split.md; round 4's form moved 106, counter-verified at 106.9 on a raster with 74 % holes,
+profiles/r04_lsqr_traffic.md) - an upper bound on rasters with few holes.
 """
 import argparse
 import json
@@ -22,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-LSQR_BYTES_PER_CELL_ITER = 106.0
+LSQR_BYTES_PER_CELL_ITER = 99.0
 
 
 def run(points=20_000_000, extent=8192.0, windows=18, cellsize=1.0, seed=20241):
@@ -85,9 +86,9 @@ def run(points=20_000_000, extent=8192.0, windows=18, cellsize=1.0, seed=20241):
     stages["points"] = points
     stages["Mpoints_per_s"] = points / stages["smrf_total_ms"] / 1e3
     stages["object_points"] = int(out[3].sum().item())          # CUDA tensors in -> CUDA tensors out
-    stages["lsqr_bytes_model"] = ("%.0f B x raster cells per iteration (DESIGN 4.3); FETCH_SIZE + WRITE_SIZE of one solve on "
-                                  "8193^2 with 74 %% holes: 106.9 B (profiles/r04_lsqr_traffic.md); ms_per_iteration is stage wall "
-                                  "time / iterations, i.e. with the solver's set-up passes and its host polls") % LSQR_BYTES_PER_CELL_ITER
+    stages["lsqr_bytes_model"] = ("%.0f B x raster cells per iteration (DESIGN 4.3: 12 plane touches + hole bytes; round 4's form: 106, "
+                                  "counter-verified at 106.9 B, profiles/r04_lsqr_traffic.md); ms_per_iteration is stage wall time / "
+                                  "iterations, i.e. with the solver's set-up pass and its host polls") % LSQR_BYTES_PER_CELL_ITER
     return stages
 
 
