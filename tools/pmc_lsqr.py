@@ -8,7 +8,7 @@ import re
 import sys
 
 base = sys.argv[1]
-info = re.search(r"LSQR n=(\d+) cells=(\d+) istop=(\d+) itn=(\d+) unknowns=(\d+) ms=([\d.]+)", open(os.path.join(base, "FETCH_SIZE.log")).read())
+info = re.search(r"LSQR n=(\d+) cells=(\d+) istop=(\d+) itn=(\d+) unknowns=(\d+) (?:event_)?ms=([\d.]+)", open(os.path.join(base, "FETCH_SIZE.log")).read())
 n, cells, istop, itn, nunk = (int(info.group(i)) for i in range(1, 6))
 val = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -30,7 +30,7 @@ print("| kernel | launches | with traffic | read GB / real launch | written GB |
 print("|---|---|---|---|---|---|---|")
 tot = 0.0
 for k in sorted(val["FETCH_SIZE"]):
-    if not re.search(r"atu_kernel|xwav_kernel|av_kernel|reduce_scalar|rhs_kernel|mask_kernel|scatter|w_init", k):
+    if not re.search(r"atu_kernel|atuxw_kernel|av2_kernel|setup_kernel|xwav_kernel|av_kernel|reduce_scalar|rhs_kernel|mask_kernel|scatter|w_init", k):
         continue
     fr = val["FETCH_SIZE"][k]
     wr = val["WRITE_SIZE"].get(k, [0.0] * len(fr))
@@ -40,7 +40,10 @@ for k in sorted(val["FETCH_SIZE"]):
     r = sum(fr[i] for i in live) * sr / len(live)
     w = sum(wr[i] for i in live if i < len(wr)) * sw / len(live)
     print("| `%s` | %d | %d | %.3f | %.3f | %.1f | %.1f |" % (k[:60], len(fr), len(live), r / 1e9, w / 1e9, r / cells, w / cells))
-    if re.search(r"atu_kernel<false>|xwav_kernel", k):
-        tot += r + w
+    if re.search(r"atu_kernel<false>|xwav_kernel", k) and not any("atuxw_kernel" in q for q in val["FETCH_SIZE"]):
+        tot += r + w                                        # round 4's iteration
+    if re.search(r"atuxw_kernel|av2_kernel", k):
+        tot += r + w                                        # round 5's: atuxw (average of the passes with and without the x step) + av2
 print()
-print("Per iteration (atu + xwav): %.2f GB = %.1f B per raster cell (model of DESIGN 4.3: 106 B)." % (tot / 1e9, tot / cells))
+print("Per iteration (atu + xwav, or since round 5 atuxw + av2): %.2f GB = %.1f B per raster cell (model of DESIGN 4.3: 99 B since round 5, "
+      "106 B for round 4's iteration)." % (tot / 1e9, tot / cells))

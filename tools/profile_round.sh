@@ -12,6 +12,8 @@ out=$(pwd)/gpurun_out/$tag
 R=$(pwd)
 mkdir -p $out
 export TMPDIR=/tmp
+part=${2:-all}          # A: the benchmark's own files; B: smrf / fp64 / band / micro-benchmarks / LSQR; all: both
+if [ "$part" != "B" ]; then
 python bench.py > $out/bench.json 2> $out/bench.err < /dev/null
 python bench.py --size 4096 --windows 18 --steps 20 --warmup 2 --cpu-crop 0 --no-pmc --no-secondary > $out/bench_4096_w18.json 2>> $out/bench.err < /dev/null
 cd /tmp
@@ -20,6 +22,8 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 $R/tools/pmc_traffic.py > /dev/null 2> $out/pmc_write.err < /dev/null
 cd $R
 bash tools/pmc_kernels.sh $out/pmc_kernels --size 16384 --windows 50
+fi
+if [ "$part" = "A" ]; then exit 0; fi
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_smrf20 -- python3 $R/tools/smrf_stages.py --points 20000000 --extent 8192 > $out/smrf_stages_20M.json 2> $out/smrf20.err < /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_smrf100 -- python3 $R/tools/smrf_stages.py --points 100000000 --extent 32768 > $out/smrf_stages_100M.json 2> $out/smrf100.err < /dev/null

@@ -7,7 +7,7 @@ all_to_all of create_dem_sharded with itself as only peer); the neighbour send /
     python tools/rccl_single_rank_check.py
 """
 import os, sys
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # the repository this file sits in
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
 os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
 import numpy as np, torch, torch.distributed as dist
