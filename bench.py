@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo stages halos through the host: for rehearsing N>1 ranks on one GPU")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal on a one-GPU box)")
+    ap.add_argument("--launch-timeout", type=int, default=1500, help="bare --gpus N: seconds the self-started ranks may take")
     return ap.parse_args()
 
 
@@ -284,13 +285,31 @@ def self_launch(a, argv):
     env.setdefault("OMP_NUM_THREADS", "4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)      # stderr passes through
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    # the ranks run in their own session: if they hang past --launch-timeout the whole group (launcher + ranks) is ended,
+    # not just the launcher - a rank left behind would keep the GPUs
+    import signal
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)      # stderr passes through
+    try:
+        stdout, _ = proc.communicate(timeout=a.launch_timeout)
+    except subprocess.TimeoutExpired:
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=20)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        fail_line("the %d ranks did not finish within %d s (--launch-timeout): process group ended" % (a.gpus, a.launch_timeout), 6,
+                  n_gpus=a.gpus)
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
     for ln in lines[-1:]:
         print(ln, flush=True)
-    if r.returncode == 0 and not lines:
+    if proc.returncode == 0 and not lines:
         fail_line("the %d ranks ended without a bench line" % a.gpus, 5, n_gpus=a.gpus)
-    sys.exit(r.returncode)
+    sys.exit(proc.returncode)
 
 
 def main():
