@@ -262,14 +262,17 @@ SMRF_API int smrf_springs_lsqr_f64(double* d_A, int rows, int cols, double atol,
  *   h_out[0] v plane, h_out[1] uv plane (rows_local + 2 rows, h_out[6] doubles apart, the first cols used; row 0 = halo above),
  *   h_out[2] hole plane (rows_local + 2 rows, h_out[6] bytes apart), h_out[6] the planes' row pitch in cells (>= cols),
  *   h_out[3] cols doubles = raster row
- *   below the band, h_out[4] two doubles = the phase's local sums (phase 3 fills both: |v|^2 and |w|^2,
+ *   below the band, h_out[4] two doubles = the phase's local sums (phase 7 fills both: |v|^2 and |dk|^2,
  *   to be all-reduced as ONE 2-element buffer; every other phase uses the first), h_out[5] total bytes.
  * Phases (in order; "<- X" = what the host must have delivered before the phase):
  *   0 mask+count | 1 rhs <- hole halo below, A row below, all-reduced count | 2 |b| <- all-reduce
- *   3 v = S^T u - beta v <- uv halo above | 4 first alfa, w <- all-reduce
- *   loop: 5 u = S v - alfa u <- v halo below | 6 beta <- all-reduce | 3 | 7 alfa + rotation <- all-reduce (2 values)
- *         8 x, w update | 9 stopping tests (|dk|^2 = |w|^2 / rho^2 from phase 3's second sum: no collective)
- *   10 scatter the solution into d_A_band.
+ *   3 first v = S^T u <- uv halo above | 4 first alfa <- all-reduce
+ *   loop (the split rotation of lsqr.py:424-555, csrc/lsqr_core.h; the single-device solver's kernels):
+ *         5 u = S v - alfa u <- v halo below | 6 beta, rho, t1 <- all-reduce
+ *         7 w, dk, (x every second iteration), v = S^T u - beta v <- uv halo above
+ *         8 alfa, rest of the rotation, stopping tests <- all-reduce (2 values)
+ *   10 scatter the solution into d_A_band (adds the pending x step when the solve stopped at an odd iteration).
+ * Two halo rows and two all-reduces per iteration, 12 plane touches (round 4's phases 5, 6, 3, 7, 8, 9: 15).
  * neilpy_amd/sharded.py drives it over torch.distributed (RCCL). */
 SMRF_API size_t smrf_springs_band_workspace_bytes(int rows_local, int cols);
 SMRF_API int smrf_springs_band_layout(int rows_local, int cols, int64_t* h_out);

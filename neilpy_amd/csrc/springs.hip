@@ -23,11 +23,6 @@
 // HBM-bound: per iteration about 3 plane reads + 2 plane writes of each of u (2 planes), v, w, x.
 #include "lsqr_core.h"
 
-// the single-device solver's iteration with the x / w / dk steps riding in the v pass (atuxw_kernel): 0 = round 4's form
-#ifndef SMRF_SPRINGS_SPLIT
-#define SMRF_SPRINGS_SPLIT 1
-#endif
-
 namespace {
 
 // One row band of the raster.  Plane pointers address the first OWN row; row -1 and row `rows` are
@@ -111,36 +106,18 @@ __global__ void s_bnorm(const Band b) {
   sc->inv_alfa = 1.0;
 }
 
-// ---- v = S^T u_s - beta * v_s  (u_s = inv_beta*u, v_s = inv_alfa*v), partial |v|^2 -----------
-// WSUM (row-band form): also the partial |w|^2 of the same cells -> part[MAXB..].  w is still the vector the
-// iteration's dk = w / rho is made of, so |dk|^2 = |w|^2 / rho^2 can ride with |v|^2 in ONE 2-element all-reduce
-// instead of a third collective after the x, w update (rho only exists once |v|^2 is reduced).
-template <bool WSUM>
+// ---- v = S^T u_s - beta * v_s  (u_s = inv_beta*u, v_s = inv_alfa*v), partial |v|^2: the set-up's first v ----------
+// (inside the iteration atuxw_kernel makes v together with the x / w / dk steps)
 __global__ __launch_bounds__(256) void atu_kernel(const Band b) {
   __shared__ double red[4];
-  __shared__ double red2[4];
   const Sc* sc = b.sc;
   if (stopped(sc)) return;
   const int rows = b.rows, cols = b.cols;
   const long long ld = b.ld;
   const LsqrTile tl = lsqr_tile(b.nxcd);
-  if (!sc->beta_pos) {
-    // beta == 0 (u = 0: the exact solution is reached): v and alfa stay as they are (lsqr.py:434-441), but the
-    // row-band form's tests still take |dk|^2 from this phase's |w|^2, so that half is written all the same
-    if constexpr (WSUM) {
-      double sw0 = 0.0;
-      SMRF_FOR_CELLS_T(tl, rows, cols, ld) {
-        if (!b.hole[i]) continue;
-        const double ws = b.w[i];
-        sw0 += ws * ws;
-      }
-      const double tw0 = block_sum(sw0, red2);
-      if (threadIdx.x == 0) b.part[MAXB + SMRF_TILE_SLOT(tl)] = tw0;
-    }
-    return;
-  }
+  if (!sc->beta_pos) return;                             // beta == 0 (b = 0): v and alfa stay as they are (lsqr.py:434-441)
   const double ib = sc->inv_beta, ia = sc->inv_alfa, beta = sc->beta;
-  double s = 0.0, sw = 0.0;
+  double s = 0.0;
   // The hole byte decides whether a cell loads anything else; it is requested one row of the walk ahead.  Worth 4 % per
   // iteration where holes are sparse (10.8 % of the cells: 1.112 -> 1.070 ms on 8193^2), nothing where they are dense.  Same
   // cells in the same order: every sum is bit-identical.  (Round 4 also built the rows' loads as ONE unconditional batch
@@ -165,7 +142,6 @@ __global__ __launch_bounds__(256) void atu_kernel(const Band b) {
           const double nv = y - beta * (ia * b.v[i]);
           b.v[i] = nv;
           s += nv * nv;
-          if constexpr (WSUM) { const double ws = b.w[i]; sw += ws * ws; }
         }
         h = hn;
       }
@@ -173,10 +149,6 @@ __global__ __launch_bounds__(256) void atu_kernel(const Band b) {
   }
   const double t = block_sum(s, red);
   if (threadIdx.x == 0) b.part[SMRF_TILE_SLOT(tl)] = t;
-  if constexpr (WSUM) {
-    const double tw = block_sum(sw, red2);
-    if (threadIdx.x == 0) b.part[MAXB + SMRF_TILE_SLOT(tl)] = tw;
-  }
 }
 
 // block partials of two sums -> red[0], red[1]
@@ -201,151 +173,7 @@ __global__ void s_init_alfa(const Band b) {
   if (a * sc->beta == 0) sc->done = 1;      // arnorm == 0: x = 0 is the answer (lsqr.py:386-390)
 }
 
-__global__ __launch_bounds__(256) void w_init_kernel(const Band b) {
-  if (b.sc->done) return;
-  const double ia = b.sc->inv_alfa;
-  SMRF_FOR_CELLS_P(b.rows, b.cols, b.ld) b.w[i] = ia * b.v[i];
-}
-
-// ---- u = S v_s - alfa * u_s, partial |u|^2 ---------------------------------------------------
-__global__ __launch_bounds__(256) void av_kernel(const Band b) {
-  __shared__ double red[4];
-  const Sc* sc = b.sc;
-  if (stopped(sc)) return;
-  const double ib = sc->inv_beta, ia = sc->inv_alfa, alfa = sc->alfa;
-  const int rows = b.rows, cols = b.cols;
-  const long long ld = b.ld;
-  double s = 0.0;
-  const LsqrTile tl = lsqr_tile(b.nxcd);
-  SMRF_FOR_CELLS_T(tl, rows, cols, ld) {
-    // v[i] is read before the hole tests on purpose: making it (or a per-tile activity byte) conditional turns
-    // independent loads into dependent ones and measured 4-10 % SLOWER on 8192^2 at every hole pattern
-    // (gpurun_out/r02/lsqr_ab*.log); planes of known-only regions are never touched as it is.
-    const bool h0 = b.hole[i];
-    const double v0 = ia * b.v[i];
-    if (c + 1 < cols) {
-      if (h0 | b.hole[i + 1]) {
-        const double nu = (v0 - ia * b.v[i + 1]) - alfa * (ib * b.uh[i]);
-        b.uh[i] = nu;
-        s += nu * nu;
-      }
-    }
-    if (r + 1 < rows || b.has_below) {
-      if (h0 | b.hole[i + ld]) {
-        const double nu = (v0 - ia * b.v[i + ld]) - alfa * (ib * b.uv[i]);
-        b.uv[i] = nu;
-        s += nu * nu;
-      }
-    }
-  }
-  const double t = block_sum(s, red);
-  if (threadIdx.x == 0) b.part[SMRF_TILE_SLOT(tl)] = t;
-}
-
-__global__ void s_beta(const Band b) {
-  if (stopped(b.sc)) return;
-  beta_step(b.sc, b.red[0]);
-}
-
-__global__ void s_alfa_rot(const Band b) {
-  if (stopped(b.sc)) return;
-  alfa_rot_step(b.sc, b.red[0]);
-}
-
-// ---- x += t1*w ; w = v_s + t2*w ; partial |w/rho|^2 ------------------------------------------
-__global__ __launch_bounds__(256) void xw_kernel(const Band b) {
-  __shared__ double red[4];
-  const Sc* sc = b.sc;
-  if (stopped(sc)) return;
-  const double t1 = sc->t1, t2 = sc->t2, ir = sc->inv_rho, ia = sc->inv_alfa;
-  double s = 0.0;
-  const LsqrTile tl = lsqr_tile(b.nxcd);
-  SMRF_FOR_CELLS_T(tl, b.rows, b.cols, b.ld) {
-    if (!b.hole[i]) continue;
-    const double ws = b.w[i];
-    const double dk = ir * ws;
-    b.x[i] = b.x[i] + t1 * ws;
-    b.w[i] = ia * b.v[i] + t2 * ws;
-    s += dk * dk;
-  }
-  const double t = block_sum(s, red);
-  if (threadIdx.x == 0) b.part[SMRF_TILE_SLOT(tl)] = t;
-}
-
-// row-band form: red[1] = all-reduced |w|^2 from the ATU phase; |dk|^2 = |w|^2 / rho^2
-__global__ void s_tests(const Band b) {
-  if (stopped(b.sc)) return;
-  tests_step(b.sc, (b.red[1] * b.sc->inv_rho) * b.sc->inv_rho);
-}
-
-// ---- single-device fast path: xw of iteration i fused with av of iteration i+1 ---------------
-// (both walk the same cells; the u update of a stopping iteration is wasted but harmless).
-// red[0] <- |w/rho|^2 (iteration i), red[1] <- |u|^2 (iteration i+1), via part[] and part[MAXB..].
-__global__ __launch_bounds__(256) void xwav_kernel(const Band b) {
-  __shared__ double red[4];
-  __shared__ double red2[4];
-  const Sc* sc = b.sc;
-  if (stopped(sc)) return;
-  const double t1 = sc->t1, t2 = sc->t2, ir = sc->inv_rho, ia = sc->inv_alfa, ib = sc->inv_beta, alfa = sc->alfa;
-  const int rows = b.rows, cols = b.cols;
-  const long long ld = b.ld;
-  double sd = 0.0, su = 0.0;
-  const LsqrTile tl = lsqr_tile(b.nxcd);
-  // the three hole bytes a cell's tests need are requested one row of the walk ahead (see atu_kernel); same cells, same order
-  {
-    const int c = tl.x * 256 + (int)threadIdx.x;
-    if (c < cols) {
-      const bool has_r = c + 1 < cols;
-      int r = tl.y;
-      uint8_t h0 = 0, h1 = 0, hd = 0;
-      if (r < rows) {
-        const long long i0 = (long long)r * ld + c;
-        h0 = b.hole[i0];
-        if (has_r) h1 = b.hole[i0 + 1];
-        if (r + 1 < rows) hd = b.hole[i0 + ld];
-      }
-      for (; r < rows; r += gridDim.y) {
-        const long long i = (long long)r * ld + c;
-        const int rn = r + (int)gridDim.y;
-        uint8_t n0 = 0, n1 = 0, nd = 0;
-        if (rn < rows) {
-          const long long in = (long long)rn * ld + c;
-          n0 = b.hole[in];
-          if (has_r) n1 = b.hole[in + 1];
-          if (rn + 1 < rows) nd = b.hole[in + ld];
-        }
-        const double v0 = ia * b.v[i];                   // unconditional on purpose (see av_kernel)
-        if (h0) {
-          const double ws = b.w[i];
-          const double dk = ir * ws;
-          b.x[i] = b.x[i] + t1 * ws;
-          b.w[i] = v0 + t2 * ws;
-          sd += dk * dk;
-        }
-        if (has_r) {
-          if (h0 | h1) {
-            const double nu = (v0 - ia * b.v[i + 1]) - alfa * (ib * b.uh[i]);
-            b.uh[i] = nu;
-            su += nu * nu;
-          }
-        }
-        if (r + 1 < rows) {
-          if (h0 | hd) {
-            const double nu = (v0 - ia * b.v[i + ld]) - alfa * (ib * b.uv[i]);
-            b.uv[i] = nu;
-            su += nu * nu;
-          }
-        }
-        h0 = n0; h1 = n1; hd = nd;
-      }
-    }
-  }
-  const double td = block_sum(sd, red);
-  const double tu = block_sum(su, red2);
-  if (threadIdx.x == 0) { b.part[SMRF_TILE_SLOT(tl)] = td; b.part[MAXB + SMRF_TILE_SLOT(tl)] = tu; }
-}
-
-// ---- single-device solver, round 5: the x / w / dk steps ride in the pass that makes v ----------------------------
+// ---- the iteration since round 5 (single device and row bands): the x / w / dk steps ride in the pass that makes v ----
 // Iteration k was [atu: v_k, |v|^2] [alfa, rotation] [xwav: x_k, w_k, |dk|^2; u_{k+1}, |u|^2] [tests; beta]: 13 plane
 // touches (atu 3 reads + 1 write, xwav 5 + 4).  The rotation's rho, phi - hence t1 = phi / rho and 1 / rho - need only
 // rhobar and beta (lsqr_core.h: rho_step), so they exist BEFORE the v pass, and that pass reads v_{k-1} and can read w_{k-2}:
@@ -358,7 +186,10 @@ __global__ __launch_bounds__(256) void xwav_kernel(const Band b) {
 // x one step behind; scatter_kernel adds t1_k w_{k-1} (w still holds it: av2 and the next atuxw return at once).
 // Every vector entry goes through the same operations on the same operands in the same order as before (x_k's two
 // roundings, w, dk, v), every partial sum runs over the same cells in the same order into the same slot: x, istop and
-// itn are bit-identical to the four-launch form (tools/lsqr_ab.py --equal; the goldens' istop / itn).
+// itn are bit-identical to round 4's four-launch form (tools/lsqr_ab.py against a round-4 build; the goldens' istop / itn).
+// The row-band form runs the same two vector kernels as phases (PH_AV, PH_ATUXW) with the host's halo rows and all-reduces
+// between them: 12 plane touches per iteration where round 4's band phases (av, atu + |w|^2, xw) made 15, and |dk|^2 is now
+// SciPy's own sum over (w / rho)^2 (round 4's band form used |w|^2 / rho^2, a rounding apart).
 __global__ __launch_bounds__(256) void atuxw_kernel(const Band b) {
   __shared__ double red[4];
   __shared__ double red2[4];
@@ -414,7 +245,7 @@ __global__ __launch_bounds__(256) void atuxw_kernel(const Band b) {
   if (threadIdx.x == 0) { b.part[SMRF_TILE_SLOT(tl)] = t; b.part[MAXB + SMRF_TILE_SLOT(tl)] = td; }
 }
 
-// u = S v_s - alfa u_s, partial |u|^2: the u half of xwav_kernel (same walk, same hole-byte prefetch)
+// ---- u = S v_s - alfa u_s, partial |u|^2 (the hole bytes a cell's tests need are requested one row of the walk ahead) ----
 __global__ __launch_bounds__(256) void av2_kernel(const Band b) {
   __shared__ double red[4];
   const Sc* sc = b.sc;
@@ -430,11 +261,12 @@ __global__ __launch_bounds__(256) void av2_kernel(const Band b) {
       const bool has_r = c + 1 < cols;
       int r = tl.y;
       uint8_t h0 = 0, h1 = 0, hd = 0;
+      const int rv = b.has_below ? rows : rows - 1;        // rows with a vertical spring below them (band form: the halo row)
       if (r < rows) {
         const long long i0 = (long long)r * ld + c;
         h0 = b.hole[i0];
         if (has_r) h1 = b.hole[i0 + 1];
-        if (r + 1 < rows) hd = b.hole[i0 + ld];
+        if (r < rv) hd = b.hole[i0 + ld];
       }
       for (; r < rows; r += gridDim.y) {
         const long long i = (long long)r * ld + c;
@@ -444,9 +276,12 @@ __global__ __launch_bounds__(256) void av2_kernel(const Band b) {
           const long long in = (long long)rn * ld + c;
           n0 = b.hole[in];
           if (has_r) n1 = b.hole[in + 1];
-          if (rn + 1 < rows) nd = b.hole[in + ld];
+          if (rn < rv) nd = b.hole[in + ld];
         }
-        const double v0 = ia * b.v[i];                   // unconditional on purpose (see av_kernel)
+        // v[i] is read before the hole tests on purpose: making it (or a per-tile activity byte) conditional turns independent
+        // loads into dependent ones and measured 4-10 % SLOWER on 8192^2 at every hole pattern (gpurun_out/r02/lsqr_ab*.log);
+        // planes of known-only regions are never touched as it is
+        const double v0 = ia * b.v[i];
         if (has_r) {
           if (h0 | h1) {
             const double nu = (v0 - ia * b.v[i + 1]) - alfa * (ib * b.uh[i]);
@@ -454,7 +289,7 @@ __global__ __launch_bounds__(256) void av2_kernel(const Band b) {
             su += nu * nu;
           }
         }
-        if (r + 1 < rows) {
+        if (r < rv) {
           if (h0 | hd) {
             const double nu = (v0 - ia * b.v[i + ld]) - alfa * (ib * b.uv[i]);
             b.uv[i] = nu;
@@ -467,6 +302,18 @@ __global__ __launch_bounds__(256) void av2_kernel(const Band b) {
   }
   const double tu = block_sum(su, red);
   if (threadIdx.x == 0) b.part[SMRF_TILE_SLOT(tl)] = tu;
+}
+
+// row-band form of the scalar steps (the host all-reduces b.red between the phases)
+__global__ void s_beta_rho(const Band b) {
+  if (stopped(b.sc)) return;
+  beta_step(b.sc, b.red[0]);
+  rho_step(b.sc);
+}
+__global__ void s_alfa_tests(const Band b) {               // red[0] = |v|^2, red[1] = |dk|^2 (one 2-element all-reduce)
+  if (stopped(b.sc)) return;
+  alfa_rest_step(b.sc, b.red[0]);
+  tests_step(b.sc, b.red[1]);
 }
 
 // set-up of the single-device solver in ONE plane pass: hole mask (from A itself: the neighbours' NaN-ness is read off the
@@ -526,9 +373,9 @@ __global__ void s_count_bnorm(const Band b) {             // red[0] = holes, red
   sc->inv_alfa = 1.0;
 }
 
-// PEND: the solve stopped at an odd iteration k - x still lacks t1_k w_{k-1} (atuxw_kernel)
-__global__ __launch_bounds__(256) void scatter_kernel(double* __restrict__ A, const Band b, int split) {
-  const bool pend = split && (b.sc->itn & 1) != 0;
+// pend: the solve stopped at an odd iteration k - x still lacks t1_k w_{k-1} (atuxw_kernel)
+__global__ __launch_bounds__(256) void scatter_kernel(double* __restrict__ A, const Band b) {
+  const bool pend = (b.sc->itn & 1) != 0;
   const double t1 = b.sc->t1;
   SMRF_FOR_CELLS_P(b.rows, b.cols, b.ld)
     if (b.hole[i]) A[(long long)r * b.cols + c] = pend ? b.x[i] + t1 * b.w[i] : b.x[i];
@@ -590,17 +437,17 @@ Band band_of(void* ws, int rows, int cols, long long ld, int has_above, int has_
   return b;
 }
 enum Phase {
-  PH_MASK = 0,      // hole mask of own rows, red[0] = local unknown count
-  PH_RHS = 1,       // (after hole/A halo + count all-reduce) rhs, red[0] = local |b|^2
-  PH_BNORM = 2,     // (after all-reduce) beta = |b|
-  PH_ATU = 3,       // (after uv halo)  v = S^T u - beta v, red[0] = local |v|^2, red[1] = local |w|^2
-  PH_INIT_ALFA = 4, // (after all-reduce) alfa, w = v
-  PH_AV = 5,        // (after v halo)   u = S v - alfa u, red[0] = local |u|^2
-  PH_BETA = 6,      // (after all-reduce)
-  PH_ALFA_ROT = 7,  // (after PH_ATU + all-reduce) alfa, plane rotation
-  PH_XW = 8,        // x, w update
-  PH_TESTS = 9,     // stopping tests (|dk|^2 = red[1] / rho^2, reduced with PH_ATU's pair), itn += 1
-  PH_SCATTER = 10,  // A[hole] = x
+  PH_MASK = 0,        // hole mask of own rows, red[0] = local unknown count
+  PH_RHS = 1,         // (after hole/A halo + count all-reduce) rhs, red[0] = local |b|^2
+  PH_BNORM = 2,       // (after all-reduce) beta = |b|
+  PH_ATU = 3,         // set-up only, (after uv halo): v = S^T u, red[0] = local |v|^2
+  PH_INIT_ALFA = 4,   // (after all-reduce) alfa
+  // one iteration (round 5: the split rotation, atuxw_kernel / av2_kernel - the single-device solver's kernels):
+  PH_AV = 5,          // (after v halo)   u = S v - alfa u, red[0] = local |u|^2
+  PH_BETA_RHO = 6,    // (after all-reduce) beta, anorm, rho_step: cs, sn, rho, t1, 1/rho
+  PH_ATUXW = 7,       // (after uv halo)  w, dk, (x every second iteration), v;  red[0] = local |v|^2, red[1] = local |dk|^2
+  PH_ALFA_TESTS = 8,  // (after ONE 2-element all-reduce) alfa, rest of the rotation, stopping tests, itn += 1
+  PH_SCATTER = 10,    // A[hole] = x (+ t1 w when the solve stopped at an odd iteration)
 };
 
 // 2-D launch of the stencil kernels: 256 columns per block, rows strided over gridDim.y; at most MAXB blocks
@@ -622,20 +469,16 @@ int run_phase(int phase, double* A, const Band& b, hipStream_t st) {
       reduce(nb2);
       break;
     case PH_BNORM: hipLaunchKernelGGL(s_bnorm, dim3(1), dim3(1), 0, st, b); break;
-    case PH_ATU:
-      hipLaunchKernelGGL(atu_kernel<true>, g2, dim3(256), 0, st, b);
+    case PH_ATU: hipLaunchKernelGGL(atu_kernel, g2, dim3(256), 0, st, b); reduce(nb2); break;
+    case PH_INIT_ALFA: hipLaunchKernelGGL(s_init_alfa, dim3(1), dim3(1), 0, st, b); break;   // (w_0 is made by the first atuxw pass)
+    case PH_AV: hipLaunchKernelGGL(av2_kernel, g2, dim3(256), 0, st, b); reduce(nb2); break;
+    case PH_BETA_RHO: hipLaunchKernelGGL(s_beta_rho, dim3(1), dim3(1), 0, st, b); break;
+    case PH_ATUXW:
+      hipLaunchKernelGGL(atuxw_kernel, g2, dim3(256), 0, st, b);
       hipLaunchKernelGGL(reduce2_kernel, dim3(1), dim3(256), 0, st, (const double*)b.part, nb2, b.red);
       break;
-    case PH_INIT_ALFA:
-      hipLaunchKernelGGL(s_init_alfa, dim3(1), dim3(1), 0, st, b);
-      hipLaunchKernelGGL(w_init_kernel, g2, dim3(256), 0, st, b);
-      break;
-    case PH_AV: hipLaunchKernelGGL(av_kernel, g2, dim3(256), 0, st, b); reduce(nb2); break;
-    case PH_BETA: hipLaunchKernelGGL(s_beta, dim3(1), dim3(1), 0, st, b); break;
-    case PH_ALFA_ROT: hipLaunchKernelGGL(s_alfa_rot, dim3(1), dim3(1), 0, st, b); break;
-    case PH_XW: hipLaunchKernelGGL(xw_kernel, g2, dim3(256), 0, st, b); break;   // its sum rode with PH_ATU's
-    case PH_TESTS: hipLaunchKernelGGL(s_tests, dim3(1), dim3(1), 0, st, b); break;
-    case PH_SCATTER: hipLaunchKernelGGL(scatter_kernel, g2, dim3(256), 0, st, A, b, 0); break;
+    case PH_ALFA_TESTS: hipLaunchKernelGGL(s_alfa_tests, dim3(1), dim3(1), 0, st, b); break;
+    case PH_SCATTER: hipLaunchKernelGGL(scatter_kernel, g2, dim3(256), 0, st, A, b); break;
     default: return smrf_fail(SMRF_E_ARG, "unknown springs phase %d", phase);
   }
   SMRF_LAUNCH_CHECK();
@@ -669,50 +512,31 @@ int smrf_springs_lsqr_f64(double* d_A, int rows, int cols, double atol, double b
   if (int rc = init_scalars(b, atol, btol, conlim, iter_lim, stream)) return rc;
   const dim3 g2 = grid2d(b);
   const int nb = (int)(g2.x * g2.y);
-#if SMRF_SPRINGS_SPLIT
   // set-up: one plane pass (mask + right-hand side + counts), the first v = S^T u, alfa; then u_1 and beta_1 + rho_step
   hipLaunchKernelGGL(setup_kernel, g2, dim3(256), 0, stream, (const double*)d_A, b);
   hipLaunchKernelGGL(reduce2_kernel, dim3(1), dim3(256), 0, stream, (const double*)b.part, nb, b.red);
   hipLaunchKernelGGL(s_count_bnorm, dim3(1), dim3(1), 0, stream, b);
-  hipLaunchKernelGGL(atu_kernel<false>, g2, dim3(256), 0, stream, b);
+  hipLaunchKernelGGL(atu_kernel, g2, dim3(256), 0, stream, b);
   hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(256), 0, stream, (const double*)b.part, nb, b.red);
   hipLaunchKernelGGL(s_init_alfa, dim3(1), dim3(1), 0, stream, b);
   SMRF_LAUNCH_CHECK();
-#else
-  for (int ph : {PH_MASK, PH_RHS, PH_BNORM, PH_ATU, PH_INIT_ALFA})
-    if (int rc = run_phase(ph, d_A, b, stream)) return rc;
-#endif
   Sc out{};
   SMRF_HIP_CHECK(hipMemcpyAsync(&out, b.sc, sizeof(out), hipMemcpyDeviceToHost, stream));
   SMRF_HIP_CHECK(hipStreamSynchronize(stream));
   const long long lim = out.iter_lim;
   if (!out.done && out.istop == 0 && out.itn < lim) {
-#if SMRF_SPRINGS_SPLIT
     hipLaunchKernelGGL(av2_kernel, g2, dim3(256), 0, stream, b);
     hipLaunchKernelGGL((reduce_scalar_kernel<4, Band>), dim3(1), dim3(256), 0, stream, b, nb);
-#else
-    hipLaunchKernelGGL(av_kernel, g2, dim3(256), 0, stream, b);
-    hipLaunchKernelGGL((reduce_scalar_kernel<0, Band>), dim3(1), dim3(256), 0, stream, b, nb);
-#endif
     SMRF_LAUNCH_CHECK();
   }
   int chunk = 4;
   while (!out.done && out.istop == 0 && out.itn < lim) {
     for (int k = 0; k < chunk; ++k) {
-#if SMRF_SPRINGS_SPLIT
       // Iteration k = [w_{k-1}, dk_k, (x), v_k] [alfa_k, rotation, tests_k] [u_{k+1}] [beta_{k+1}, rho_{k+1}]  (atuxw_kernel)
       hipLaunchKernelGGL(atuxw_kernel, g2, dim3(256), 0, stream, b);
       hipLaunchKernelGGL((reduce_scalar_kernel<3, Band>), dim3(1), dim3(256), 0, stream, b, nb);
       hipLaunchKernelGGL(av2_kernel, g2, dim3(256), 0, stream, b);
       hipLaunchKernelGGL((reduce_scalar_kernel<4, Band>), dim3(1), dim3(256), 0, stream, b, nb);
-#else
-      // Iteration i = [u = S v - alfa u; beta] [v = S^T u - beta v; alfa, rotation] [x, w update; tests].
-      // Four launches per iteration: atu | reduce+alfa_rot | xw(i) fused with av(i+1) | reduce+tests(i)+beta(i+1).
-      hipLaunchKernelGGL(atu_kernel<false>, g2, dim3(256), 0, stream, b);
-      hipLaunchKernelGGL((reduce_scalar_kernel<1, Band>), dim3(1), dim3(256), 0, stream, b, nb);
-      hipLaunchKernelGGL(xwav_kernel, g2, dim3(256), 0, stream, b);
-      hipLaunchKernelGGL((reduce_scalar_kernel<2, Band>), dim3(1), dim3(256), 0, stream, b, nb);
-#endif
     }
     SMRF_LAUNCH_CHECK();
     SMRF_HIP_CHECK(hipMemcpyAsync(&out, b.sc, sizeof(out), hipMemcpyDeviceToHost, stream));
@@ -720,7 +544,7 @@ int smrf_springs_lsqr_f64(double* d_A, int rows, int cols, double atol, double b
     chunk = std::min(32, chunk * 2);
   }
   if (out.nunk > 0) {
-    hipLaunchKernelGGL(scatter_kernel, g2, dim3(256), 0, stream, d_A, b, SMRF_SPRINGS_SPLIT);
+    hipLaunchKernelGGL(scatter_kernel, g2, dim3(256), 0, stream, d_A, b);
     SMRF_LAUNCH_CHECK();
     SMRF_HIP_CHECK(hipStreamSynchronize(stream));
   }

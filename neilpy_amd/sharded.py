@@ -371,7 +371,9 @@ def progressive_filter_sharded(Z_band, img_rows, windows, thresholds, *, rank=No
 # ------------------------------------------------------------------------------------------
 # inpaint_nans_by_springs over row bands: 1-row halos + one scalar all-reduce per reduction
 # ------------------------------------------------------------------------------------------
-PH_MASK, PH_RHS, PH_BNORM, PH_ATU, PH_INIT_ALFA, PH_AV, PH_BETA, PH_ALFA_ROT, PH_XW, PH_TESTS, PH_SCATTER = range(11)
+# phases of smrf_springs_band_phase (include/smrf_hip.h; 9 is retired)
+PH_MASK, PH_RHS, PH_BNORM, PH_ATU, PH_INIT_ALFA, PH_AV, PH_BETA_RHO, PH_ATUXW, PH_ALFA_TESTS = range(9)
+PH_SCATTER = 10
 
 
 class HipSpringsOps:
@@ -396,7 +398,7 @@ class HipSpringsOps:
         self.uv = self.ws[lay[1]:lay[1] + n2 * 8].view(torch.float64).view(self.rows + 2, ld)[:, :self.cols]
         self.hole = self.ws[lay[2]:lay[2] + n2].view(self.rows + 2, ld)[:, :self.cols]
         self.abelow = self.ws[lay[3]:lay[3] + self.cols * 8].view(torch.float64)
-        self.red2 = self.ws[lay[4]:lay[4] + 16].view(torch.float64)      # [|v|^2, |w|^2] of the ATU phase
+        self.red2 = self.ws[lay[4]:lay[4] + 16].view(torch.float64)      # [|v|^2, |dk|^2] of the ATUXW phase
         self.red = self.red2[:1]                                          # the single sum of the other phases
 
     def _stream(self):
@@ -458,10 +460,10 @@ def inpaint_nans_by_springs_sharded(A_band, img_rows, *, rank=None, world_size=N
 
     Per LSQR iteration: rank r sends the first row of ``v`` up and the last row of ``uv`` down (one
     row each, nearest neighbour) and TWO all-reduces replace the three norms: ``|u|^2`` alone (beta
-    must exist before ``v = S^T u - beta v``), then ``[|v|^2, |w|^2]`` as one 2-element buffer -
-    ``|dk|^2 = |w|^2 / rho^2`` with ``w`` the vector before this iteration's update, so it needs no
-    collective of its own after ``rho`` is known (lsqr.py:455-461 computes ``norm(w / rho)``; the two
-    differ by a rounding in ``ddnorm``, which only feeds the condition-number test).  Two
+    must exist before ``v = S^T u - beta v``), then ``[|v|^2, |dk|^2]`` as one 2-element buffer:
+    the plane rotation's ``rho`` needs only ``rhobar`` and ``beta`` (csrc/lsqr_core.h: rho_step), so
+    ``dk = w / rho`` (lsqr.py:459) - and with it the x and w steps - ride in the pass that makes
+    ``v`` (csrc/springs.hip: atuxw_kernel, the single-device solver's kernel; round 5).  Two
     synchronisation points per iteration is LSQR's own minimum (beta, then alfa).  The scalar
     recurrence runs replicated on every rank from the same reduced sums, so all ranks stop at the
     same iteration.  Summation order differs from one device (block partials per band), so
@@ -507,16 +509,14 @@ def inpaint_nans_by_springs_sharded(A_band, img_rows, *, rank=None, world_size=N
         for _ in range(poll):
             if multi:
                 _shift(dist, group, rank, world_size, ops.v[1], ops.v[n + 1], up=True)
-            ops.phase(PH_AV)
+            ops.phase(PH_AV)                                 # u_k = S v_{k-1} - alfa u_{k-1}
             reduce()
-            ops.phase(PH_BETA)
+            ops.phase(PH_BETA_RHO)                           # beta_k; rho_k, t1_k, 1/rho_k need nothing else
             if multi:
                 _shift(dist, group, rank, world_size, ops.uv[n], ops.uv[0], up=False)
-            ops.phase(PH_ATU)
-            reduce2()
-            ops.phase(PH_ALFA_ROT)
-            ops.phase(PH_XW)
-            ops.phase(PH_TESTS)
+            ops.phase(PH_ATUXW)                              # w_{k-1}, dk_k, (x_k every second k), v_k
+            reduce2()                                        # [|v|^2, |dk|^2] as one buffer
+            ops.phase(PH_ALFA_TESTS)                         # alfa_k, rest of the rotation, stopping tests
         istop, itn, nunk, done = ops.status()
     if nunk > 0:
         ops.phase(PH_SCATTER)

@@ -29,7 +29,7 @@ class NumpySpringsOps:
         self.v, self.uh, self.uv = torch.zeros(n2, dtype=torch.float64), np.zeros(n2), torch.zeros(n2, dtype=torch.float64)
         self.hole = torch.zeros(n2, dtype=torch.uint8)
         self.abelow = torch.zeros(self.cols, dtype=torch.float64)
-        self.red2 = torch.zeros(2, dtype=torch.float64)   # [|v|^2, |w|^2] of phase 3; the other phases use red[0]
+        self.red2 = torch.zeros(2, dtype=torch.float64)   # [|v|^2, |dk|^2] of phase 7; the other phases use red[0]
         self.red = self.red2[:1]
         self.sc = {}
 
@@ -40,6 +40,23 @@ class NumpySpringsOps:
 
     def _stopped(self):
         return self.sc["done"] or self.sc["istop"] != 0
+
+    def _aty(self):
+        """S^T u_s on the own rows, the four springs of a cell in the kernels' order (up, left, right, down)"""
+        s, n = self.sc, self.rows
+        own = slice(1, n + 1)
+        uv = self.uv.numpy()
+        y = np.zeros((n, self.cols))
+        up = s["ib"] * uv[0:n]
+        if not self.ha:
+            up[0] = 0.0
+        y = y - up
+        y[:, 1:] = y[:, 1:] - s["ib"] * self.uh[own][:, :-1]
+        y[:, :-1] = y[:, :-1] + s["ib"] * self.uh[own][:, :-1]
+        dn = s["ib"] * uv[own]
+        if not self.hb:
+            dn[-1] = 0.0
+        return y + dn
 
     def phase(self, ph):
         s, n = self.sc, self.rows
@@ -71,25 +88,13 @@ class NumpySpringsOps:
         elif ph == 2:
             b = sqrt(float(self.red[0]))
             s.update(bnorm=b, beta=b, beta_pos=b > 0, ib=1 / b if b > 0 else 1.0, alfa=0.0, ia=1.0)
-        elif ph == 3:
+        elif ph == 3:                                          # set-up: the first v = S^T u (v = 0 before)
             if self._stopped() or not s["beta_pos"]:
                 return
             h = hole[own].astype(bool)
-            y = np.zeros((n, self.cols))
-            up = s["ib"] * uv[0:n]
-            if not self.ha:
-                up[0] = 0.0
-            y = y - up
-            y[:, 1:] = y[:, 1:] - s["ib"] * self.uh[own][:, :-1]
-            y[:, :-1] = y[:, :-1] + s["ib"] * self.uh[own][:, :-1]
-            dn = s["ib"] * uv[own]
-            if not self.hb:
-                dn[-1] = 0.0
-            y = y + dn
-            nv = np.where(h, y - s["beta"] * (s["ia"] * v[own]), v[own])
+            nv = np.where(h, self._aty() - s["beta"] * (s["ia"] * v[own]), v[own])
             v[own] = nv
             self.red[0] = float((nv[h] * nv[h]).sum())
-            self.red2[1] = float((self.w[own][h] ** 2).sum())       # |w|^2 rides with |v|^2 (w before this iteration's update)
         elif ph == 4:
             if s["done"]:
                 return
@@ -97,9 +102,7 @@ class NumpySpringsOps:
             s.update(alfa=a, ia=1 / a if a > 0 else 1.0, rhobar=a, phibar=s["beta"])
             if a * s["beta"] == 0:
                 s["done"] = True
-                return
-            self.w[own] = s["ia"] * v[own]
-        elif ph == 5:
+        elif ph == 5:                                          # u = S v - alfa u
             if self._stopped():
                 return
             h = hole[own].astype(bool)
@@ -118,7 +121,7 @@ class NumpySpringsOps:
             uv[own] = np.where(actv, nuv, uv[own])
             tot += float((nuv[actv] ** 2).sum())
             self.red[0] = tot
-        elif ph == 6:
+        elif ph == 6:                                          # beta, then the part of the rotation that needs only rhobar and beta
             if self._stopped():
                 return
             b = sqrt(float(self.red[0]))
@@ -128,20 +131,39 @@ class NumpySpringsOps:
                 s["anorm"] = sqrt(s["anorm"] ** 2 + s["alfa"] ** 2 + b ** 2)
             else:
                 s["ib"] = 1.0
-        elif ph == 7:
+            from oracle.smrf_oracle import _sym_ortho
+            cs, sn, rho = _sym_ortho(s["rhobar"], s["beta"])
+            phi = cs * s["phibar"]
+            s.update(cs=cs, sn=sn, rho=rho, phi=phi, t1_prev=s.get("t1", 0.0), t1=phi / rho, ir=1 / rho)
+        elif ph == 7:                                          # w_{k-1}, dk_k, (x every second iteration: both steps), v_k
+            if self._stopped():
+                return
+            h = hole[own].astype(bool)
+            vs = s["ia"] * v[own]
+            wo = self.w[own].copy()
+            first, xupd = s["itn"] == 0, (s["itn"] & 1) != 0
+            wn = vs if first else vs + s["t2"] * wo
+            if xupd:
+                self.x[own] = np.where(h, (self.x[own] + s["t1_prev"] * wo) + s["t1"] * wn, self.x[own])
+            self.w[own] = np.where(h, wn, self.w[own])
+            dk = s["ir"] * wn
+            self.red2[1] = float((dk[h] ** 2).sum())
+            if s["beta_pos"]:
+                nv = np.where(h, self._aty() - s["beta"] * vs, v[own])
+                v[own] = nv
+                self.red[0] = float((nv[h] * nv[h]).sum())
+        elif ph == 8:                                          # alfa, the rest of the rotation, the stopping tests
             if self._stopped():
                 return
             if s["beta_pos"]:
                 a = sqrt(float(self.red[0]))
                 s.update(alfa=a, ia=1 / a if a > 0 else 1.0)
-            from oracle.smrf_oracle import _sym_ortho
-            cs, sn, rho = _sym_ortho(s["rhobar"], s["beta"])
+            cs, sn, rho, phi = s["cs"], s["sn"], s["rho"], s["phi"]
             theta = sn * s["alfa"]
             s["rhobar"] = -cs * s["alfa"]
-            phi = cs * s["phibar"]
             s["phibar"] = sn * s["phibar"]
             s["tau"] = sn * phi
-            s.update(t1=phi / rho, t2=-theta / rho, ir=1 / rho)
+            s["t2"] = -theta / rho
             delta, gambar = s["sn2"] * rho, -s["cs2"] * rho
             rhs = phi - delta * s["z"]
             zbar = rhs / gambar
@@ -149,18 +171,8 @@ class NumpySpringsOps:
             gamma = sqrt(gambar ** 2 + theta ** 2)
             s.update(cs2=gambar / gamma, sn2=theta / gamma, z=rhs / gamma)
             s["xxnorm"] = s["xxnorm"] + s["z"] ** 2
-        elif ph == 8:
-            if self._stopped():
-                return
-            h = hole[own].astype(bool)
-            ws = self.w[own].copy()
-            self.x[own] = np.where(h, self.x[own] + s["t1"] * ws, self.x[own])
-            self.w[own] = np.where(h, s["ia"] * v[own] + s["t2"] * ws, self.w[own])
-        elif ph == 9:
-            if self._stopped():
-                return
             EPS = np.finfo(np.float64).eps
-            nd = sqrt((float(self.red2[1]) * s["ir"]) * s["ir"])       # |dk|^2 = |w|^2 / rho^2
+            nd = sqrt(float(self.red2[1]))                          # |dk|^2, all-reduced with |v|^2
             s["ddnorm"] += nd * nd
             s["itn"] += 1
             acond = s["anorm"] * sqrt(s["ddnorm"])
@@ -180,9 +192,10 @@ class NumpySpringsOps:
             if test2 <= s["atol"]: istop = 2
             if test1 <= rtol: istop = 1
             s["istop"] = istop
-        elif ph == 10:
+        elif ph == 10:                                         # a solve that stopped at an odd iteration owes x its last step
             h = hole[own].astype(bool)
-            A[h] = self.x[own][h]
+            xs = self.x[own] + s["t1"] * self.w[own] if (s["itn"] & 1) else self.x[own]
+            A[h] = xs[h]
 
     def status(self):
         s = self.sc
