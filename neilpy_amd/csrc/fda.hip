@@ -97,7 +97,38 @@ __global__ void fda_bnorm(const Fda b) {
   sc->inv_alfa = 1.0;
 }
 
-// v = A^T u_s - beta * v_s on the NaN cells, partial |v|^2
+// A^T u_s on one NaN cell: the equations whose stencil holds it, each cnt times, in SciPy's CSC order
+__device__ __forceinline__ double fda_col_dot(const Fda& b, long long i, int r, int c, double ib) {
+  const int rows = b.rows, cols = b.cols;
+  double y = 0.0;
+  if (r >= 1 && has_v(b, r - 1)) {                      // the row above holds this cell as its "down" entry
+    const double t = ib * b.u[i - cols];
+    for (int k = b.cnt[i - cols]; k > 0; --k) y = y + t;
+  }
+  if (c >= 1 && has_h(b, c - 1)) {
+    const double t = ib * b.u[i - 1];
+    for (int k = b.cnt[i - 1]; k > 0; --k) y = y + t;
+  }
+  {
+    const bool pv = has_v(b, r), ph = has_h(b, c);
+    if (pv | ph) {
+      const double cc = -2.0 * ((pv ? 1 : 0) + (ph ? 1 : 0));
+      const double t = cc * (ib * b.u[i]);
+      for (int k = b.cnt[i]; k > 0; --k) y = y + t;
+    }
+  }
+  if (c + 1 < cols && has_h(b, c + 1)) {
+    const double t = ib * b.u[i + 1];
+    for (int k = b.cnt[i + 1]; k > 0; --k) y = y + t;
+  }
+  if (r + 1 < rows && has_v(b, r + 1)) {
+    const double t = ib * b.u[i + cols];
+    for (int k = b.cnt[i + cols]; k > 0; --k) y = y + t;
+  }
+  return y;
+}
+
+// v = A^T u_s - beta * v_s on the NaN cells, partial |v|^2 (the set-up's first v; smrf_fda_apply_f64)
 __global__ __launch_bounds__(256) void fda_atu_kernel(const Fda b) {
   __shared__ double red[4];
   const Sc* sc = b.sc;
@@ -108,37 +139,53 @@ __global__ __launch_bounds__(256) void fda_atu_kernel(const Fda b) {
   const LsqrTile tl = lsqr_tile(b.nxcd);                      // XCD-aware placement of the walk (lsqr_core.h)
   SMRF_FOR_CELLS_T(tl, rows, cols, cols) {
     if (!b.hole[i]) continue;
-    double y = 0.0;
-    if (r >= 1 && has_v(b, r - 1)) {                      // the row above holds this cell as its "down" entry
-      const double t = ib * b.u[i - cols];
-      for (int k = b.cnt[i - cols]; k > 0; --k) y = y + t;
-    }
-    if (c >= 1 && has_h(b, c - 1)) {
-      const double t = ib * b.u[i - 1];
-      for (int k = b.cnt[i - 1]; k > 0; --k) y = y + t;
-    }
-    {
-      const bool pv = has_v(b, r), ph = has_h(b, c);
-      if (pv | ph) {
-        const double cc = -2.0 * ((pv ? 1 : 0) + (ph ? 1 : 0));
-        const double t = cc * (ib * b.u[i]);
-        for (int k = b.cnt[i]; k > 0; --k) y = y + t;
-      }
-    }
-    if (c + 1 < cols && has_h(b, c + 1)) {
-      const double t = ib * b.u[i + 1];
-      for (int k = b.cnt[i + 1]; k > 0; --k) y = y + t;
-    }
-    if (r + 1 < rows && has_v(b, r + 1)) {
-      const double t = ib * b.u[i + cols];
-      for (int k = b.cnt[i + cols]; k > 0; --k) y = y + t;
-    }
-    const double nv = y - beta * (ia * b.v[i]);
+    const double nv = fda_col_dot(b, i, r, c, ib) - beta * (ia * b.v[i]);
     b.v[i] = nv;
     s += nv * nv;
   }
   const double t = block_sum(s, red);
   if (threadIdx.x == 0) b.part[SMRF_TILE_SLOT(tl)] = t;
+}
+
+// The iteration's v pass with the x / w / dk steps riding in it (round 5; springs.hip: atuxw_kernel has the derivation):
+//   w_{k-1} = v_{k-1} / alfa_{k-1} + t2_{k-1} w_{k-2} (k = 1: w_0 = v_0 / alfa_0), dk_k = w_{k-1} / rho_k, |dk|^2,
+//   k even: x_k = (x_{k-2} + t1_{k-1} w_{k-2}) + t1_k w_{k-1};  v_k = A^T u_k - beta_k v_{k-1}, |v|^2.
+// part[0..] <- |v|^2, part[MAXB..] <- |dk|^2.  Same operations per entry and the same cells per partial sum as the
+// xw + atu passes it replaces: x, istop, itn are bit-identical.
+__global__ __launch_bounds__(256) void fda_atuxw_kernel(const Fda b) {
+  __shared__ double red[4];
+  __shared__ double red2[4];
+  const Sc* sc = b.sc;
+  if (stopped(sc)) return;
+  const long long itn = sc->itn;
+  const bool first = itn == 0, xupd = (itn & 1) != 0, bpos = sc->beta_pos != 0;
+  const double ib = sc->inv_beta, ia = sc->inv_alfa, beta = sc->beta;
+  const double t1 = sc->t1, t1p = sc->t1_prev, t2 = sc->t2, ir = sc->inv_rho;
+  double s = 0.0, sd = 0.0;
+  const LsqrTile tl = lsqr_tile(b.nxcd);
+  SMRF_FOR_CELLS_T(tl, b.rows, b.cols, b.cols) {
+    if (!b.hole[i]) continue;
+    const double vs = ia * b.v[i];
+    double wn;
+    if (first) {
+      wn = vs;
+    } else {
+      const double wo = b.w[i];
+      wn = vs + t2 * wo;
+      if (xupd) b.x[i] = (b.x[i] + t1p * wo) + t1 * wn;
+    }
+    b.w[i] = wn;
+    const double dk = ir * wn;
+    sd += dk * dk;
+    if (bpos) {
+      const double nv = fda_col_dot(b, i, r, c, ib) - beta * vs;
+      b.v[i] = nv;
+      s += nv * nv;
+    }
+  }
+  const double t = block_sum(s, red);
+  const double td = block_sum(sd, red2);
+  if (threadIdx.x == 0) { b.part[SMRF_TILE_SLOT(tl)] = t; b.part[MAXB + SMRF_TILE_SLOT(tl)] = td; }
 }
 
 __global__ void fda_init_alfa(const Fda b) {
@@ -150,13 +197,6 @@ __global__ void fda_init_alfa(const Fda b) {
   sc->rhobar = a;
   sc->phibar = sc->beta;
   if (a * sc->beta == 0) sc->done = 1;      // arnorm == 0: x = 0 is the answer (lsqr.py:386-390)
-}
-
-__global__ __launch_bounds__(256) void fda_w_init_kernel(const Fda b) {
-  if (b.sc->done) return;
-  const double ia = b.sc->inv_alfa;
-  const long long n = (long long)b.rows * b.cols;
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) b.w[i] = ia * b.v[i];
 }
 
 // A v_s on one equation cell (ascending flat index of the stencil's NaN cells)
@@ -172,7 +212,7 @@ __device__ __forceinline__ double fda_row_dot(const Fda& b, long long i, int r, 
   return y;
 }
 
-// first u = A v_s - alfa * u_s (before the fused loop), partial |u|^2
+// u = A v_s - alfa * u_s, partial |u|^2
 __global__ __launch_bounds__(256) void fda_av_kernel(const Fda b) {
   __shared__ double red[4];
   const Sc* sc = b.sc;
@@ -191,40 +231,12 @@ __global__ __launch_bounds__(256) void fda_av_kernel(const Fda b) {
   if (threadIdx.x == 0) b.part[SMRF_TILE_SLOT(tl)] = t;
 }
 
-// x += t1*w ; w = v_s + t2*w (iteration i) fused with u = A v_s - alfa*u_s (iteration i+1): v is
-// only read here.  part[0..] <- |w/rho|^2, part[MAXB..] <- |u|^2
-__global__ __launch_bounds__(256) void fda_xwav_kernel(const Fda b) {
-  __shared__ double red[4];
-  __shared__ double red2[4];
-  const Sc* sc = b.sc;
-  if (stopped(sc)) return;
-  const double t1 = sc->t1, t2 = sc->t2, ir = sc->inv_rho, ia = sc->inv_alfa, ib = sc->inv_beta, alfa = sc->alfa;
-  double sd = 0.0, su = 0.0;
-  const LsqrTile tl = lsqr_tile(b.nxcd);                      // XCD-aware placement of the walk (lsqr_core.h)
-  SMRF_FOR_CELLS_T(tl, b.rows, b.cols, b.cols) {
-    if (b.hole[i]) {
-      const double ws = b.w[i];
-      const double dk = ir * ws;
-      b.x[i] = b.x[i] + t1 * ws;
-      b.w[i] = ia * b.v[i] + t2 * ws;
-      sd += dk * dk;
-    }
-    const int cnt = b.cnt[i];
-    if (cnt != 0) {
-      const double nu = fda_row_dot(b, i, r, c, ia) - alfa * (ib * b.u[i]);
-      b.u[i] = nu;
-      su += cnt * (nu * nu);
-    }
-  }
-  const double td = block_sum(sd, red);
-  const double tu = block_sum(su, red2);
-  if (threadIdx.x == 0) { b.part[SMRF_TILE_SLOT(tl)] = td; b.part[MAXB + SMRF_TILE_SLOT(tl)] = tu; }
-}
-
 __global__ __launch_bounds__(256) void fda_scatter_kernel(double* __restrict__ A, const Fda b) {
   const long long n = (long long)b.rows * b.cols;
+  const bool pend = (b.sc->itn & 1) != 0;                 // stopped at an odd iteration: x still lacks t1_k w_{k-1} (fda_atuxw_kernel)
+  const double t1 = b.sc->t1;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-    if (b.hole[i]) A[i] = b.x[i];
+    if (b.hole[i]) A[i] = pend ? b.x[i] + t1 * b.w[i] : b.x[i];
 }
 
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -293,27 +305,25 @@ int smrf_fda_lsqr_f64(double* d_A, int rows, int cols, double atol, double btol,
   hipLaunchKernelGGL(fda_atu_kernel, g2, dim3(256), 0, stream, b);
   reduce(nb);
   hipLaunchKernelGGL(fda_init_alfa, dim3(1), dim3(1), 0, stream, b);
-  hipLaunchKernelGGL(fda_w_init_kernel, dim3(nb1), dim3(256), 0, stream, b);
   SMRF_LAUNCH_CHECK();
 
   Sc out{};
   SMRF_HIP_CHECK(hipMemcpyAsync(&out, b.sc, sizeof(out), hipMemcpyDeviceToHost, stream));
   SMRF_HIP_CHECK(hipStreamSynchronize(stream));
   const long long lim = out.iter_lim;
-  // Iteration i = [u = A v - alfa u; beta] [v = A^T u - beta v; alfa, rotation] [x, w update; tests]:
-  // atu | reduce+alfa_rot | xw(i) fused with av(i+1) | reduce+tests(i)+beta(i+1), as in springs.hip
+  // Iteration k = [w_{k-1}, dk_k, (x), v_k] [alfa_k, rotation, tests_k] [u_{k+1}] [beta_{k+1}, rho_{k+1}], as in springs.hip
   if (!out.done && out.istop == 0 && out.itn < lim) {
     hipLaunchKernelGGL(fda_av_kernel, g2, dim3(256), 0, stream, b);
-    hipLaunchKernelGGL((reduce_scalar_kernel<0, Fda>), dim3(1), dim3(256), 0, stream, b, nb);
+    hipLaunchKernelGGL((reduce_scalar_kernel<4, Fda>), dim3(1), dim3(256), 0, stream, b, nb);
     SMRF_LAUNCH_CHECK();
   }
   int chunk = 4;
   while (!out.done && out.istop == 0 && out.itn < lim) {
     for (int k = 0; k < chunk; ++k) {
-      hipLaunchKernelGGL(fda_atu_kernel, g2, dim3(256), 0, stream, b);
-      hipLaunchKernelGGL((reduce_scalar_kernel<1, Fda>), dim3(1), dim3(256), 0, stream, b, nb);
-      hipLaunchKernelGGL(fda_xwav_kernel, g2, dim3(256), 0, stream, b);
-      hipLaunchKernelGGL((reduce_scalar_kernel<2, Fda>), dim3(1), dim3(256), 0, stream, b, nb);
+      hipLaunchKernelGGL(fda_atuxw_kernel, g2, dim3(256), 0, stream, b);
+      hipLaunchKernelGGL((reduce_scalar_kernel<3, Fda>), dim3(1), dim3(256), 0, stream, b, nb);
+      hipLaunchKernelGGL(fda_av_kernel, g2, dim3(256), 0, stream, b);
+      hipLaunchKernelGGL((reduce_scalar_kernel<4, Fda>), dim3(1), dim3(256), 0, stream, b, nb);
     }
     SMRF_LAUNCH_CHECK();
     SMRF_HIP_CHECK(hipMemcpyAsync(&out, b.sc, sizeof(out), hipMemcpyDeviceToHost, stream));

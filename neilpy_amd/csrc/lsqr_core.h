@@ -121,48 +121,12 @@ __device__ void beta_step(Sc* sc, double sum_u) {
 
 __device__ __forceinline__ double sgn(double a) { return a > 0 ? 1.0 : (a < 0 ? -1.0 : 0.0); }
 
-__device__ void alfa_rot_step(Sc* sc, double sum_v) {
-  if (sc->beta_pos) {
-    const double a = sqrt(sum_v);
-    sc->alfa = a;
-    sc->inv_alfa = a > 0 ? 1 / a : 1.0;
-  }
-  const double alfa = sc->alfa, beta = sc->beta;
-  // cs, sn, rho = _sym_ortho(rhobar, beta)   (lsqr.py:62-94)
-  const double a = sc->rhobar, b = beta;
-  double cs, sn, rho;
-  if (b == 0) { cs = sgn(a); sn = 0; rho = fabs(a); }
-  else if (a == 0) { cs = 0; sn = sgn(b); rho = fabs(b); }
-  else if (fabs(b) > fabs(a)) { const double tau = a / b; sn = sgn(b) / sqrt(1 + tau * tau); cs = sn * tau; rho = b / sn; }
-  else { const double tau = b / a; cs = sgn(a) / sqrt(1 + tau * tau); sn = cs * tau; rho = a / cs; }
-  const double theta = sn * alfa;
-  sc->rhobar = -cs * alfa;
-  const double phi = cs * sc->phibar;
-  sc->phibar = sn * sc->phibar;
-  const double tau = sn * phi;
-  sc->t1 = phi / rho;
-  sc->t2 = -theta / rho;
-  sc->inv_rho = 1 / rho;
-  // the norm(x) estimate (lsqr.py:474-483)
-  const double delta = sc->sn2 * rho;
-  const double gambar = -sc->cs2 * rho;
-  const double rhs = phi - delta * sc->z;
-  const double zbar = rhs / gambar;
-  const double xnorm = sqrt(sc->xxnorm + zbar * zbar);
-  const double gamma = sqrt(gambar * gambar + theta * theta);
-  sc->cs2 = gambar / gamma;
-  sc->sn2 = theta / gamma;
-  sc->z = rhs / gamma;
-  sc->xxnorm = sc->xxnorm + sc->z * sc->z;
-  sc->xnorm = xnorm;   // for the stopping tests
-  sc->tau = tau;
-}
-
-// alfa_rot_step in two halves (springs.hip, single-device solver): the plane rotation (lsqr.py:62-94, 443-451) needs only
-// rhobar and beta - so cs, sn, rho, phi and with them t1 = phi / rho and 1 / rho exist as soon as |u|^2 is reduced, one
-// vector pass BEFORE alfa does.  That lets the x and dk = w / rho steps of iteration k ride in the pass that makes v_k (which
-// reads the old v and w anyway) instead of the pass after it.  Same operations on the same operands in the same order per
-// quantity as alfa_rot_step: every scalar is bit-identical.
+// The plane rotation and what follows it (lsqr.py:443-483) in two halves: cs, sn, rho, phi - hence t1 = phi / rho and
+// 1 / rho - need only rhobar and beta, so they exist as soon as |u|^2 is reduced (rho_step), one vector pass BEFORE alfa
+// does; the rest needs alfa (alfa_rest_step).  That lets the x and dk = w / rho steps of iteration k ride in the pass that
+// makes v_k (which reads the old v and w anyway) instead of a pass of their own.  Same operations on the same operands in
+// the same order per quantity as SciPy's loop body: every scalar is bit-identical
+// (tests/test_host_logic.py::test_split_rotation_equals_alfa_rot_step replays both orders in Python floats).
 __device__ void rho_step(Sc* sc) {                         // right after beta_step of the same iteration
   const double a = sc->rhobar, b = sc->beta;
   double cs, sn, rho;
@@ -230,10 +194,11 @@ __device__ void tests_step(Sc* sc, double sum_dk) {
   sc->istop = istop;
 }
 
-// reduce the block partials and run the scalar step(s) in the same launch (one block)
-// WHAT 3, 4 (split rotation): 3 = part[] -> alfa + rest of the rotation, part[MAXB..] -> tests;  4 = part[] -> beta + rho_step
-template <int WHAT, typename B>   // 0: beta   1: alfa + rotation   2: tests(i) then beta(i+1);  B has .part and .sc
+// reduce the block partials and run the scalar steps in the same launch (one block)
+// WHAT 3: part[] = |v|^2 -> alfa + rest of the rotation, part[MAXB..] = |dk|^2 -> tests;  4: part[] = |u|^2 -> beta + rho_step
+template <int WHAT, typename B>   // B has .part and .sc
 __global__ __launch_bounds__(256) void reduce_scalar_kernel(const B b, int nb) {
+  static_assert(WHAT == 3 || WHAT == 4, "3: alfa + tests, 4: beta + rho");
   __shared__ double red[4];
   __shared__ double red2[4];
   Sc* sc = b.sc;
@@ -241,17 +206,11 @@ __global__ __launch_bounds__(256) void reduce_scalar_kernel(const B b, int nb) {
   double s0 = 0.0, s1 = 0.0;
   for (int i = threadIdx.x; i < nb; i += 256) {
     s0 += b.part[i];
-    if (WHAT == 2 || WHAT == 3) s1 += b.part[MAXB + i];
+    if (WHAT == 3) s1 += b.part[MAXB + i];
   }
   const double t0 = block_sum(s0, red);
-  const double t1 = (WHAT == 2 || WHAT == 3) ? block_sum(s1, red2) : 0.0;
+  const double t1 = WHAT == 3 ? block_sum(s1, red2) : 0.0;
   if (threadIdx.x == 0) {
-    if (WHAT == 0) beta_step(sc, t0);
-    if (WHAT == 1) alfa_rot_step(sc, t0);
-    if (WHAT == 2) {
-      tests_step(sc, t0);
-      if (sc->istop == 0) beta_step(sc, t1);
-    }
     if (WHAT == 3) {
       alfa_rest_step(sc, t0);
       tests_step(sc, t1);

@@ -621,3 +621,24 @@ def test_sharded_entry_points_over_one_rank_rccl(nz):
     assert "max |band - single device| 0.0" in out
     assert "create_dem_sharded equal True True" in out
     assert "self send/recv of a row block over RCCL equal True" in out
+
+
+def test_band_lsqr_on_one_rank_is_the_single_device_solve(nz, gpu_device):
+    """round 5: the row-band phases (smrf_springs_band_phase: PH_AV, PH_BETA_RHO, PH_ATUXW, PH_ALFA_TESTS) run the single-device
+    solver's own vector kernels, so a band that is the whole raster gives the same bits, the same istop and itn - whether the
+    solve stops at an even or an odd iteration (the odd ones owe x one step, added by the scatter)"""
+    import torch
+    from neilpy_amd import sharded
+    seen = set()
+    for n, holes, seed in ((257, 0.6, 1), (300, 0.3, 2), (513, 0.8, 3), (199, 0.5, 4), (401, 0.1, 5)):
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        Z = torch.from_numpy(nz.synth_dem(n, seed=seed).astype(np.float64)).to(gpu_device)
+        Z[torch.rand((n, n), device="cuda", generator=g) < holes] = float("nan")
+        ref = nz.inpaint_nans_by_springs(Z)
+        st = dict(nz.last_stats["inpaint"])
+        A = Z.clone()
+        istop, itn, nunk = sharded.inpaint_nans_by_springs_sharded(A, n, rank=0, world_size=1)
+        assert (istop, itn, nunk) == (st["istop"], st["itn"], st["n_unknown"])
+        assert torch.equal(A, ref), (n, holes, float((A - ref).abs().max()))
+        seen.add(itn & 1)
+    assert seen == {0, 1}, "the cases should stop at both parities"
