@@ -264,9 +264,9 @@ __device__ __forceinline__ void op3_acc(double& acc, double b, double c) { acc =
 
 // The window steps of one lookup group as ONE asm statement (fp32, one read per side for every width of the group): width
 // k's two minima grown from width k-1's, N widths chained,
-//     x[i] = op3(x[i-1], x[i], u[i]),  y[i] = op3(y[i-1], y[i], w[i])        (x[-1] = a0, y[-1] = b0)
-// in place in the registers the first read of every width arrived in ({x[i], y[i]} = the ds_read_b64 of the window's left
-// end, {u[i], w[i]} the one of its right end).  Written one op3 per asm statement, every step that reads the one before it
+//     x[i] = op3(x[i-1], tx[i], u[i]),  y[i] = op3(y[i-1], ty[i], w[i])      (x[-1] = a0, y[-1] = b0)
+// ({tx[i], ty[i]} = the ds_read_b64 of width i's left end, rows A and B; {u[i], w[i]} the one of its right end; results in
+// early-clobber outputs).  Written one op3 per asm statement, every step that reads the one before it
 // costs an `s_nop 0`: hipcc counts no wait states for asm statements (they have no known length) and assumes gfx950's
 // dst_sel forwarding hazard between an asm that writes a register and the next asm that reads it - two to three nops per
 // group beside 12-14 min / max (15 per 64-cell row at R = 50).  Inside one statement nothing is inserted, and the
