@@ -77,13 +77,15 @@ def survey(a):
         jobs = [(R, kind, dil, mode, tmp) for R in range(lo, hi + 1) for kind in (0, 1) for dil in (0, 1) for mode in (0, 1, 3)]
         with ThreadPoolExecutor(max_workers=a.j) as ex:
             res = list(ex.map(compile_one, jobs))
-    out = {}
+    out = json.load(open(SURVEY)) if os.path.exists(SURVEY) else {}      # a partial --radii run updates its radii only
+    for R in range(lo, hi + 1):
+        out.pop(str(R), None)
     for (R, kind, dil, mode), rec in res:
         if rec is not None:
             out.setdefault(str(R), {}).setdefault(str(kind), {}).setdefault(str(dil), {})[str(mode)] = rec
     os.makedirs(os.path.dirname(SURVEY), exist_ok=True)
     json.dump(out, open(SURVEY, "w"), indent=0, sort_keys=True)
-    for R in sorted(out, key=int):
+    for R in sorted((r for r in out if lo <= int(r) <= hi), key=int):
         for kind in sorted(out[R]):
             d = out[R][kind]
             print("R=%s %s NP=%d: " % (R, "in-place" if d["0"]["0"]["inplace"] else "shifting", d["0"]["0"]["np"]) + "  ".join(
