@@ -84,7 +84,10 @@ def survey(a):
         if rec is not None:
             out.setdefault(str(R), {}).setdefault(str(kind), {}).setdefault(str(dil), {})[str(mode)] = rec
     os.makedirs(os.path.dirname(SURVEY), exist_ok=True)
-    json.dump(out, open(SURVEY, "w"), indent=0, sort_keys=True)
+    with open(SURVEY, "w") as f:                          # one line per radius
+        keys = sorted(out, key=int)
+        f.write("{\n" + ",\n".join(" %s: %s" % (json.dumps(k), json.dumps(out[k], sort_keys=True, separators=(",", ":"))) for k in keys)
+                + "\n}\n")
     for R in sorted((r for r in out if lo <= int(r) <= hi), key=int):
         for kind in sorted(out[R]):
             d = out[R][kind]
