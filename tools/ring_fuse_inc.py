@@ -3,7 +3,7 @@
 instance the library holds, from the compiled code alone (no GPU), and write csrc/ring_fuse.inc.
 
     python tools/ring_fuse_inc.py survey [-j 8] [--radii 15-64]      -> profiles/tuning/r05_ring_fuse_survey.json
-    python tools/ring_fuse_inc.py inc [--deny 34,35] [--allow-only ...]  -> neilpy_amd/csrc/ring_fuse.inc
+    python tools/ring_fuse_inc.py inc [--deny 34,41] [--cap 46:1]          -> neilpy_amd/csrc/ring_fuse.inc
 
 For a radius's shifting instance and (where ring_inpl.inc marks it dual) its in-place instance, erosion and dilation + flag,
 each compiled with mode 0 (neither), 1 (fused steps) and 3 (fused steps + slots one group late): VGPRs, scratch bytes,
