@@ -295,7 +295,7 @@ int fused_launch(const DiskArgs<T>& a_in, hipStream_t stream) {
   const int strips = (a.cols + TWO - 1) / TWO;
   if (a.seg <= 0) {
     const int rounds = smrf_sw().fused_rounds;
-    const int nseg = std::max(1, (rounds * resident * 256 + strips / 2) / strips);   // one round: every workgroup resident
+    const int nseg = std::max(1, (rounds * resident * 256 + (smrf_sw().seg_nearest ? strips / 2 : 0)) / strips);   // one round: every workgroup resident
     int seg = (a.out_rows + nseg - 1) / nseg;
     seg = std::max(seg, std::max(32, 8 * R));             // a segment re-reads 4R warm-up rows
     seg = std::min(seg, a.out_rows);

@@ -75,6 +75,9 @@
 #ifndef SMRF_RING_XCD_REMAP
 #define SMRF_RING_XCD_REMAP 1   // XCD-aware tile placement (see ring_kernel)
 #endif
+#ifndef SMRF_RING_SLOPE_DEFAULT
+#define SMRF_RING_SLOPE_DEFAULT 60  // permille of segment length per residency class (ring_launch_np); SMRF_RING_SLOPE overrides
+#endif
 #ifndef SMRF_RING_OCC_DROP
 #define SMRF_RING_OCC_DROP 0   // tuning builds: run every radius one occupancy step below the estimate
 #endif
@@ -1297,10 +1300,22 @@ void ring_kernel(const DiskArgs<T> a) {
 #ifdef SMRF_RING_DBG_CLOCK   // timing experiment only: the shader clock this workgroup ran at, left in the output's first two cells
   const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_q0 = __builtin_amdgcn_s_memrealtime();
 #endif
+#ifdef SMRF_RING_DBG_TS
+  const unsigned long long dbg_ts0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int x0 = bx * TW;
   const int x = x0 + tid;
-  const int ys = a.out_row0 + by * a.seg;                // global output rows [ys, ye)
-  const int ye = min(a.out_row0 + a.out_rows, ys + a.seg);
+  int ys, ye;                                            // global output rows [ys, ye)
+  if (a.seg_cls > 0) {                                   // segments of unequal length (ring_launch_np: residency classes)
+    int cls = 0;
+    for (int c = 1; c < a.seg_cls; ++c) cls += by >= a.seg_first[c] ? 1 : 0;
+    ys = a.out_row0 + a.seg_row0[cls] + (by - a.seg_first[cls]) * a.seg_len[cls];
+    ye = min(a.out_row0 + a.out_rows, ys + a.seg_len[cls]);
+    if (ys >= ye) return;                                // (lengths are rounded up: a trailing segment may be empty)
+  } else {
+    ys = a.out_row0 + by * a.seg;
+    ye = min(a.out_row0 + a.out_rows, ys + a.seg);
+  }
   constexpr int NPOS = C::NPOS, W = C::W;
   // lane-owned staged cells: positions tid + i*TW of the TW+2R wide row; only the last can be absent
   const bool has_last = tid + (NPOS - 1) * TW < W;
@@ -1619,6 +1634,21 @@ void ring_kernel(const DiskArgs<T> a) {
     const int nb = (ye + R - ystart + ROWS - 1) / ROWS;
     epilogue(ystart + (nb - 1) * ROWS);
   }
+#ifdef SMRF_RING_DBG_TS   // timing experiment only (tools/experiments/ring_tails.py): when and where this workgroup ran, left in
+  if (tid == 0 && x0 + 6 <= a.cols) {   // the first cells of its segment's first row (the RESULT IS WRONG there)
+    __threadfence();
+    unsigned xcc, hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    T* const o = a.out + (long long)(ys - a.out_row0) * a.ld + x0;
+    o[0] = (T)(float)(dbg_ts0 & 0x7fffff);
+    o[1] = (T)(float)(__builtin_amdgcn_s_memrealtime() & 0x7fffff);
+    o[2] = (T)(float)(xcc & 0xf);
+    o[3] = (T)(float)(hwid & 0xffff);
+    o[4] = (T)(float)(blockIdx.y * gridDim.x + blockIdx.x);
+    o[5] = (T)(float)(ye - ys);
+  }
+#endif
 #ifdef SMRF_RING_DBG_CLOCK
   if (bx == gridDim.x / 2 && by == gridDim.y / 2 && tid == 0) {
     __threadfence();
@@ -1661,24 +1691,81 @@ int ring_launch_np(const DiskArgs<T>& a_in, hipStream_t stream, bool probe_only,
     // the fastest from radius 20 up and as fast as any below (tools/ring_tune.py cur@SMRF_RING_ROUNDS=n);
     // segments stay long enough that the 2R halo rows each one re-reads are a small part
     const int rounds = smrf_sw().ring_rounds;
-    const int nseg = std::max(1, (rounds * resident * 256 + strips / 2) / strips);
+    const int nseg = std::max(1, (rounds * resident * 256 + (smrf_sw().seg_nearest ? strips / 2 : 0)) / strips);
     int seg = (a.out_rows + nseg - 1) / nseg;
     seg = std::max(seg, std::max(32, 4 * R));
     seg = std::min(seg, a.out_rows);
     a.seg = seg;
   }
   a.seg = ((a.seg + C::ROWS - 1) / C::ROWS) * C::ROWS;
+  const int seg_equal = a.seg;
+  int grid_y = (a.out_rows + a.seg - 1) / a.seg;
+  // Segments of unequal length.  All workgroups of a one-round launch start within ~1 us, but they do not run at one speed:
+  // a CU's SIMDs issue oldest wave first, so the workgroup that reached a CU first finishes first - measured per workgroup
+  // (tools/experiments/ring_tails.py, profiles/r05_segment_balance.md): the k-th workgroup of a CU takes 5-9 % longer than the
+  // (k-1)-th at every radius, the launch lasts as long as the youngest, and the workgroups are resident for only 0.87-0.90 of
+  // it on average.  Workgroups are dealt to the CUs in dispatch order, 256 at a time (8 XCDs x 32 CUs), and ring_kernel's tile
+  // mapping makes `by` grow with the dispatch id: segment `by` is of residency class (by * strips + strips / 2) / 256 (where most
+  // of its workgroups are), and the segments of class c get 1 + slope * ((classes - 1) / 2 - c) times the mean length.  Any
+  // segmentation gives the same bits.
+  a.seg_cls = 0;
+  {
+    // Measured (profiles/r05_segment_balance.md): -1.4 ... -2.1 % of the 16384^2 step at 60 permille per class (40 ... 100 are
+    // within 0.3 % of it), nothing for fp64 (its classes differ by 3 %), and -1 ... +1 % where the classes do not fall on
+    // whole rows of segments (strips does not divide 256) - so the built-in slope is for fp32 rasters whose strips do;
+    // SMRF_RING_SLOPE=n asks for n whatever the shape.
+    const int slope_env = smrf_sw().ring_slope;
+    const int slope = slope_env >= 0 ? slope_env : (sizeof(T) == 4 && 256 % strips == 0 ? SMRF_RING_SLOPE_DEFAULT : 0);
+    const bool one_round = a_in.seg <= 0 && smrf_sw().ring_rounds == 1;
+    const auto cls_of = [&](int by) { return std::min(7, (int)(((long long)by * strips + strips / 2) / 256)); };
+    const int ncls = cls_of(grid_y - 1) + 1;
+    if (slope > 0 && one_round && strips <= 256 && ncls >= 2) {
+      int n[8] = {0};
+      for (int by = 0; by < grid_y; ++by) n[cls_of(by)]++;
+      double wsum = 0.0, w[8];
+      for (int c = 0; c < ncls; ++c) {
+        w[c] = 1.0 + 1e-3 * slope * (0.5 * (ncls - 1) - c);
+        wsum += w[c] * n[c];
+      }
+      const double base = (double)a.out_rows / wsum;
+      int first = 0, row0 = 0, longest = 0;
+      bool ok = true;
+      for (int c = 0; c < 8; ++c) {
+        int len = C::ROWS;
+        if (c < ncls) {
+          len = std::max(1, (int)(base * w[c] / C::ROWS + 0.999)) * C::ROWS;      // up to a multiple of the batch
+          ok = ok && n[c] > 0 && 2 * len >= std::max(32, 4 * R);
+        }
+        a.seg_first[c] = c < ncls ? first : grid_y;
+        a.seg_row0[c] = row0;
+        a.seg_len[c] = len;
+        if (c < ncls) {
+          first += n[c];
+          row0 += n[c] * len;
+          longest = std::max(longest, len);
+        }
+      }
+      if (ok && row0 >= a.out_rows) {
+        a.seg_cls = ncls;
+        a.seg = longest;                                                    // what the span clamp below looks at
+      }
+    }
+  }
   if constexpr (ring_buf_on<T, R, TW, NP>()) {
     // buffer addressing: a workgroup's row offsets are 32-bit (and not range-checked by the hardware): keep the span of
     // a segment (its rows + warm-up + one batch) below 2 GiB
     const long long rowb = (long long)a.ld * (long long)sizeof(T);
     const long long max_rows = ((1ll << 31) - 1) / rowb - (4 * R + 4 * C::ROWS);
     if (max_rows < C::ROWS) return smrf_fail(SMRF_E_UNSUPPORTED, "raster rows of %lld bytes are too long for this build", rowb);
-    if (a.seg > max_rows) a.seg = (int)(max_rows / C::ROWS) * C::ROWS;
+    if (a.seg > max_rows) {
+      a.seg_cls = 0;
+      a.seg = std::min(seg_equal, (int)(max_rows / C::ROWS) * C::ROWS);
+    }
   }
-  if (seg_if_launched) *seg_if_launched = a.seg;
+  if (a.seg_cls == 0) grid_y = (a.out_rows + a.seg - 1) / a.seg;
+  if (seg_if_launched) *seg_if_launched = a.seg_cls ? seg_equal : a.seg;   // (the dual rule looks at the mean length)
   if (probe_only) return SMRF_OK;
-  dim3 grid(strips, (a.out_rows + a.seg - 1) / a.seg);
+  dim3 grid(strips, grid_y);
   hipLaunchKernelGGL(kern, grid, dim3(TW), C::LDS_BYTES, stream, a);
   SMRF_LAUNCH_CHECK();
   return SMRF_OK;

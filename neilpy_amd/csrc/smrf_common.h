@@ -40,6 +40,8 @@ struct SmrfSwitches {
   int ring_seg;       // SMRF_RING_SEG: output rows per workgroup (0 = from the occupancy)
   int ring_dual;      // SMRF_RING_DUAL: -1 by segment length, 0 shifting ring, 1 in-place ring
   int ring_rounds, fused_rounds, chain_rounds;   // workgroups per resident slot
+  int seg_nearest;    // SMRF_SEG_NEAREST=1: rounds x resident x 256 / strips segments rounded to nearest (rounds 1-4's rule) instead of down
+  int ring_slope;     // SMRF_RING_SLOPE: permille of segment length per residency class (-1 = the library's rule, 0 = equal segments)
   int ring_debug;     // SMRF_RING_DEBUG: print each instance's geometry once
 };
 SMRF_HIDDEN const SmrfSwitches& smrf_sw();
@@ -80,6 +82,11 @@ struct DiskArgs {
   int seg;            // output rows per workgroup (ring kernels)
   int nt;             // output cells as non-temporal (streaming) stores: planes far larger than the caches
   int dense;          // flag step writes EVERY mask / when byte (0 included): the planes need no clearing first
+  // segments of unequal length (ring kernels, round 5): seg_cls = number of classes (0: every segment is `seg` rows); class c
+  // holds the segments seg_first[c] .. seg_first[c + 1] - 1, each seg_len[c] rows, the first at out_row0 + seg_row0[c].
+  // See ring_launch_np.
+  int seg_cls;
+  int seg_first[8], seg_row0[8], seg_len[8];
 };
 
 // ring-kernel dispatchers, one per (dtype, radius % SMRF_RING_PARTS); defined in ring_part.hip.

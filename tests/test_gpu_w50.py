@@ -253,3 +253,57 @@ def test_window_routes_f64(nz, orc, gpu_device, monkeypatch):
     assert torch.equal(m0, m2) and torch.equal(m0, m4) and torch.equal(w0, w2) and torch.equal(w0, w4)
     want, want_w = orc.progressive_filter(Zh, win, 1, .15, return_when_dropped=True)
     assert np.array_equal(m2.cpu().numpy().astype(bool), want) and np.array_equal(w2.cpu().numpy(), want_w)
+
+
+def test_unequal_segments_give_the_same_bits(nz, gpu_device, monkeypatch):
+    """round 5 (morph_ring.h ring_launch_np, profiles/r05_segment_balance.md): a one-round ring launch cuts the rows into
+    segments whose length depends on the residency class of their workgroups (SMRF_RING_SLOPE, permille of the mean length
+    per class; built in: 60 for fp32 rasters whose strip count divides 256).  Placement only: erosion, dilation and the
+    window step of a 6000 x 4096 raster (16 strips: the built-in rule applies, 2..8 classes per radius) and of a
+    6000 x 4100 one (17 strips: the classes do not fall on whole rows of segments; only an explicit slope cuts it
+    unequally) are the same bits with equal segments (0), the built-in rule, 60 and an exaggerated slope whose lengths
+    are mostly rounding."""
+    import torch
+    for cols in (4096, 4100):
+        Z = torch.from_numpy(nz.synth_dem(cols, seed=31, rows=6000)).to(gpu_device)
+        Zd = Z[:3000].double()
+        radii = (2, 5, 13, 18, 25, 39, 50, 64)
+        want = {}
+        for slope in (0, None, 60, 300):
+            switch(monkeypatch, "SMRF_RING_SLOPE", slope)
+            for r in radii:
+                got = [nz.erosion(Z, radius=r, impl=1), nz.dilation(Z, radius=r, impl=1)]
+                if r in (5, 18, 39):
+                    got += [nz.erosion(Zd, radius=r, impl=1), nz.dilation(Zd, radius=r, impl=1)]
+                if slope == 0:
+                    want[r] = got
+                else:
+                    assert all(torch.equal(g, w) for g, w in zip(got, want[r])), (cols, slope, r)
+            win = np.array([3, 12, 20, 33, 47])
+            m = nz.progressive_filter(Z, win, 1, .15)
+            if slope == 0:
+                want["pf"] = m
+                switch(monkeypatch, "SMRF_RING_ROUNDS", 2)       # (more than one round: equal segments whatever the slope)
+                assert torch.equal(nz.erosion(Z, radius=18, impl=1), want[18][0])
+                switch(monkeypatch, "SMRF_RING_ROUNDS", None)
+            else:
+                assert torch.equal(m, want["pf"]), (cols, slope)
+        for r in (5, 18):                                         # and the equal-segment result is the direct kernel's
+            switch(monkeypatch, "SMRF_RING_SLOPE", 0)
+            assert torch.equal(nz.erosion(Z[:1500], radius=r, impl=2), nz.erosion(Z[:1500], radius=r, impl=1))
+
+
+def test_segment_count_rounds_down(nz, gpu_device, monkeypatch):
+    """round 5: a launch sized for one round of resident workgroups holds floor(slots / strips) rows of segments, not the
+    nearest count - 33 strips x 16 segments = 528 workgroups on 512 slots ran 16 of them in a second round that lasted
+    as long again (8193^2 fp32, all windows: 25.7 -> 21.8 ms; fp64: 99.9 -> 64.5 ms).  SMRF_SEG_NEAREST=1 is the old
+    rule: the same bits either way, on a raster whose strip count (33) makes the two rules differ at most radii."""
+    import torch
+    Z = torch.from_numpy(nz.synth_dem(8193, seed=32, rows=3000)).to(gpu_device)
+    win = np.array([1, 2, 3, 6, 9, 12, 14, 18, 33, 50])
+    want = nz.progressive_filter(Z, win, 1, .15)
+    e = {r: nz.erosion(Z, radius=r, impl=1) for r in (7, 18, 50)}
+    switch(monkeypatch, "SMRF_SEG_NEAREST", 1)
+    assert torch.equal(nz.progressive_filter(Z, win, 1, .15), want)
+    for r, w in e.items():
+        assert torch.equal(nz.erosion(Z, radius=r, impl=1), w), r
