@@ -31,6 +31,9 @@ device times (max over ranks per step), ``ms_per_step`` their MEDIAN and ``value
                 valu_inst_per_cell, shader_clock_ghz and valu_frac = VALU instructions x 4.1 cycles / (1024 SIMDs x
                 clock x the class's time): the fraction of the VALU ISSUE bound, the on-chip bound the large disks sit on
   secondary_bound  the two-pass class's pair: frac of the VALU issue bound beside its fraction of 8 TB/s
+  power         package power (W) and shader clock while the step runs back to back for 2.5 s after the timed region,
+                beside the power cap (amdgpu hwmon files, tools/gpu_power.py): the step runs AT the cap - the firmware
+                lowers the clock to hold it, which is why the issue fraction does not turn into time
 ``secondary`` (N = 1, after the headline; SURVEY 8d's secondary metric): full device smrf() on 20 M synthetic points
   (per-stage ms, points/s, LSQR ms and GB/s per iteration) and the fp64 progressive_filter 8192^2 windows 1..18 rate
   (fp64 is the dtype the reference's smrf runs in, neilpy.py:1136).
@@ -61,6 +64,7 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--cpu-crop", type=int, default=192, help="crop edge for the CPU baseline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-power", action="store_true", help="skip the 2.5 s package-power leg after the timed region (roofline.power)")
     ap.add_argument("--no-pmc", action="store_true", help="do not collect roofline.traffic / the VALU counters live (three rocprofv3 "
                     "--pmc child runs, ~1 min); quote profiles/pmc_summary.json instead")
     ap.add_argument("--no-secondary", action="store_true", help="skip the smrf() / fp64 secondary block")
@@ -91,6 +95,40 @@ def cpu_baseline(Z_crop, windows, cellsize, slope):
     except Exception as e:  # noqa: BLE001  (the single-thread figure above is the baseline; this one is extra)
         out["all_cores"] = {"error": repr(e)[:200]}
     return out
+
+
+def power_leg(step, barrier, dev, seconds=2.5):
+    """Package power and shader clock while the step runs back to back for ``seconds`` AFTER the timed region (the hwmon
+    figure is a firmware average that lags a 0.7 s region): tools/gpu_power.py reads the amdgpu hwmon files of this device
+    from a thread.  None where the files are not there.  profiles/r05_power_bound.md: every launch class of the step sits at
+    1.33-1.37 kW of the 1.4 kW cap and the firmware lowers the shader clock to hold it - the bound under the VALU issue
+    bound."""
+    import importlib.util
+    try:
+        spec = importlib.util.spec_from_file_location("gpu_power", os.path.join(ROOT, "tools", "gpu_power.py"))
+        gp = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(gp)
+        smp = gp.Sampler(dev.index or 0, 0.01)
+        if not smp.ok:
+            return None
+        smp.start()
+        t0 = time.time()
+        while time.time() - t0 < seconds:
+            for _ in range(3):
+                step()
+            barrier()
+        t1 = time.time()
+        smp.stop()
+        rec = smp.between(t0 + min(1.0, seconds / 2), t1)
+        if rec is None:
+            return None
+        rec["cap_w"] = smp.cap_w()
+        rec["frac_of_cap"] = rec["socket_w"] / rec["cap_w"] if rec["cap_w"] else None
+        rec["source"] = ("amdgpu hwmon power1_input / power1_cap / freq1_input of this device, every 10 ms while the step ran back to "
+                         "back for %.1f s after the timed region (first second dropped: the figure is a firmware average)" % seconds)
+        return rec
+    except Exception as e:  # noqa: BLE001  (a measurement aid: the headline does not depend on it)
+        return {"error": repr(e)[:200]}
 
 
 def pmc_live(n, windows, dtype, timeout_s=150):
@@ -397,6 +435,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     step_ms = np.array([evs[k].elapsed_time(evs[k + 1]) for k in range(a.steps)], dtype=np.float64)
+    power = power_leg(step, barrier, dev) if world == 1 and not a.no_power else None
     n_obj = int(mask.sum().item())
     per_rank = None
     if world > 1:
@@ -511,6 +550,8 @@ def main():
                          "device_copy_gbps": copy_gbps, "frac_of_device_copy": achieved / copy_gbps,
                          "classes": classes, "window_ms": window_ms},
         }
+        if power is not None:
+            out["roofline"]["power"] = power
         if classes and valu:
             # The on-chip bound beside the HBM one (SURVEY 8d "on-chip secondary bound"): the VALU issue port.  Per class:
             # thread-level VALU instructions per cell and window (= wave instructions per 64-cell row) from SQ_INSTS_VALU, the
