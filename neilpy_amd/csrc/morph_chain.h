@@ -472,10 +472,8 @@ int chain_launch(const ChainArgs<T>& a_in, hipStream_t stream) {
     // (chain 4, 5: 2.4 waves per SIMD measured where 4 were expected), and a launch sized for exactly one round then
     // runs a second, mostly empty one; with three the tail is short whatever the residency (chain 4, 5: 1.17 -> 0.87 ms)
     const int rounds = smrf_sw().chain_rounds;
-    const int nseg = std::max(1, (rounds * resident * 256 + (smrf_sw().seg_nearest ? strips / 2 : 0)) / strips);
+    const int nseg = smrf_pick_nseg(a.out_rows, strips, resident, rounds, 2 * C::S, C::ROWS, std::max(32, 4 * C::S), smrf_sw().seg_rule);
     int seg = (a.out_rows + nseg - 1) / nseg;
-    seg = std::max(seg, std::max(32, 4 * C::S));           // a segment re-reads 2S warm-up rows
-    seg = std::min(seg, a.out_rows);
     a.seg = seg;
   }
   a.seg = ((a.seg + C::ROWS - 1) / C::ROWS) * C::ROWS;

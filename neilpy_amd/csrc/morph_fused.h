@@ -295,10 +295,9 @@ int fused_launch(const DiskArgs<T>& a_in, hipStream_t stream) {
   const int strips = (a.cols + TWO - 1) / TWO;
   if (a.seg <= 0) {
     const int rounds = smrf_sw().fused_rounds;
-    const int nseg = std::max(1, (rounds * resident * 256 + (smrf_sw().seg_nearest ? strips / 2 : 0)) / strips);   // one round: every workgroup resident
+    // one round: every workgroup resident; a segment re-reads 4R warm-up rows (smrf_pick_nseg, smrf_common.h)
+    const int nseg = smrf_pick_nseg(a.out_rows, strips, resident, rounds, 4 * R, C::ROWS, std::max(32, 8 * R), smrf_sw().seg_rule);
     int seg = (a.out_rows + nseg - 1) / nseg;
-    seg = std::max(seg, std::max(32, 8 * R));             // a segment re-reads 4R warm-up rows
-    seg = std::min(seg, a.out_rows);
     a.seg = seg;
   }
   a.seg = ((a.seg + C::ROWS - 1) / C::ROWS) * C::ROWS;

@@ -1686,15 +1686,13 @@ int ring_launch_np(const DiskArgs<T>& a_in, hipStream_t stream, bool probe_only,
   DiskArgs<T> a = a_in;
   const int strips = (a.cols + TW - 1) / TW;
   if (a.seg <= 0) {
-    // output rows per workgroup: `rounds` workgroups per resident slot of the 256 CUs.  One round
-    // (every workgroup resident at once, the longest segments, the fewest re-read halo rows) is
-    // the fastest from radius 20 up and as fast as any below (tools/ring_tune.py cur@SMRF_RING_ROUNDS=n);
-    // segments stay long enough that the 2R halo rows each one re-reads are a small part
+    // output rows per workgroup: one round (every workgroup resident at once, the longest segments, the fewest re-read
+    // halo rows) is the fastest from radius 20 up and as fast as any below (tools/ring_tune.py cur@SMRF_RING_ROUNDS=n);
+    // how many rows of segments that round holds - all slots on a large raster, the CUs k times over on a small one -
+    // is smrf_pick_nseg's cost model (smrf_common.h)
     const int rounds = smrf_sw().ring_rounds;
-    const int nseg = std::max(1, (rounds * resident * 256 + (smrf_sw().seg_nearest ? strips / 2 : 0)) / strips);
+    const int nseg = smrf_pick_nseg(a.out_rows, strips, resident, rounds, 2 * R, C::ROWS, std::max(32, 4 * R), smrf_sw().seg_rule);
     int seg = (a.out_rows + nseg - 1) / nseg;
-    seg = std::max(seg, std::max(32, 4 * R));
-    seg = std::min(seg, a.out_rows);
     a.seg = seg;
   }
   a.seg = ((a.seg + C::ROWS - 1) / C::ROWS) * C::ROWS;
@@ -1783,7 +1781,7 @@ int ring_launch(const DiskArgs<T>& a_in, hipStream_t stream) {
     static_assert(NPI != NP, "a dual radius needs two different instances");
     static_assert(RingCfg<T, R, TW, NPI>::INPLACE && !RingCfg<T, R, TW, NP>::INPLACE, "dual instances mixed up");
     const int mode = smrf_sw().ring_dual;    // tests / A-B runs: 0 = shifting ring, 1 = in place, -1 = by rule
-    int seg = 0;
+    int seg = a_in.seg;                      // (a forced segment length is judged like the library's own)
     if (mode != 0 && a_in.seg <= 0) {
       if (int rc = ring_launch_np<T, R, DIL, NPI>(a_in, stream, true, &seg)) return rc;
     }

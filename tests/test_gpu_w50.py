@@ -296,14 +296,20 @@ def test_unequal_segments_give_the_same_bits(nz, gpu_device, monkeypatch):
 def test_segment_count_rounds_down(nz, gpu_device, monkeypatch):
     """round 5: a launch sized for one round of resident workgroups holds floor(slots / strips) rows of segments, not the
     nearest count - 33 strips x 16 segments = 528 workgroups on 512 slots ran 16 of them in a second round that lasted
-    as long again (8193^2 fp32, all windows: 25.7 -> 21.8 ms; fp64: 99.9 -> 64.5 ms).  SMRF_SEG_NEAREST=1 is the old
-    rule: the same bits either way, on a raster whose strip count (33) makes the two rules differ at most radii."""
+    as long again (8193^2 fp32, all windows: 25.7 -> 21.8 ms; fp64: 99.9 -> 64.5 ms); and a raster too small to give
+    every slot a long segment is cut so that its workgroups fill the CUs k times exactly (smrf_pick_nseg,
+    smrf_common.h).  SMRF_SEG_RULE=1 is rounds 1-4's rule, 2 the rounded-down full round with the 4R minimum: the same
+    bits under all three, on a raster whose strip count (33) makes them differ at most radii and on a small one."""
     import torch
     Z = torch.from_numpy(nz.synth_dem(8193, seed=32, rows=3000)).to(gpu_device)
     win = np.array([1, 2, 3, 6, 9, 12, 14, 18, 33, 50])
     want = nz.progressive_filter(Z, win, 1, .15)
     e = {r: nz.erosion(Z, radius=r, impl=1) for r in (7, 18, 50)}
-    switch(monkeypatch, "SMRF_SEG_NEAREST", 1)
-    assert torch.equal(nz.progressive_filter(Z, win, 1, .15), want)
-    for r, w in e.items():
-        assert torch.equal(nz.erosion(Z, radius=r, impl=1), w), r
+    Zs = Z[:700, :1500].contiguous()
+    want_s = nz.progressive_filter(Zs, win, 1, .15)
+    for rule in (1, 2):
+        switch(monkeypatch, "SMRF_SEG_RULE", rule)
+        assert torch.equal(nz.progressive_filter(Z, win, 1, .15), want), rule
+        assert torch.equal(nz.progressive_filter(Zs, win, 1, .15), want_s), rule
+        for r, w in e.items():
+            assert torch.equal(nz.erosion(Z, radius=r, impl=1), w), (rule, r)

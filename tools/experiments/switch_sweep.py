@@ -4,7 +4,7 @@ SMRF_RING_SLOPE: segments of unequal length, morph_ring.h ring_launch_np) in ONE
 re-read between calls (smrf_switches_reload), the values take turns at going first.  Masks are compared with the first value's.
 
     python tools/experiments/switch_sweep.py --slopes 0,40,60,80 --shapes 16384x16384 --first 15 --windows 50 [--fused 0]
-    python tools/experiments/switch_sweep.py --switch SMRF_SEG_NEAREST --slopes 1,0 --shapes 8193x8193,10000x12000
+    python tools/experiments/switch_sweep.py --switch SMRF_SEG_RULE --slopes 2,0 --shapes 8193x8193,10000x12000
 """
 import argparse
 import ctypes as C
