@@ -17,7 +17,7 @@ if [ "$part" != "B" ]; then
 python bench.py > $out/bench.json 2> $out/bench.err < /dev/null
 python bench.py --size 4096 --windows 18 --steps 20 --warmup 2 --cpu-crop 0 --no-pmc --no-secondary > $out/bench_4096_w18.json 2>> $out/bench.err < /dev/null
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $R/bench.py --steps 3 --no-cpu --no-pmc --no-secondary > $out/bench_under_rocprof.json 2> $out/trace.err < /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $R/bench.py --steps 3 --no-cpu --no-pmc --no-secondary --no-power > $out/bench_under_rocprof.json 2> $out/trace.err < /dev/null
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 $R/tools/pmc_traffic.py > /dev/null 2> $out/pmc_fetch.err < /dev/null
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 $R/tools/pmc_traffic.py > /dev/null 2> $out/pmc_write.err < /dev/null
 cd $R
