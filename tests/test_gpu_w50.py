@@ -291,6 +291,21 @@ def test_unequal_segments_give_the_same_bits(nz, gpu_device, monkeypatch):
         for r in (5, 18):                                         # and the equal-segment result is the direct kernel's
             switch(monkeypatch, "SMRF_RING_SLOPE", 0)
             assert torch.equal(nz.erosion(Z[:1500], radius=r, impl=2), nz.erosion(Z[:1500], radius=r, impl=1))
+        # the row-band form of the C ABI (halo rows given, out_row0 > 0): the classes start at the band's first output row
+        import ctypes as C
+        from neilpy_amd import _lib
+        lib = _lib.load()
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        b0, b1 = 1000, 5000
+        for r in (18, 39):
+            lo, hi = b0 - r, b1 + r
+            src = Z[lo:hi]
+            for slope in (None, 300):
+                switch(monkeypatch, "SMRF_RING_SLOPE", slope)
+                out = torch.empty((b1 - b0, cols), dtype=Z.dtype, device=gpu_device)
+                _lib.check(lib.smrf_disk_filter_f32(C.c_void_p(src.data_ptr()), C.c_void_p(out.data_ptr()), 6000, cols, cols, lo,
+                                                    hi - lo, b0, b1 - b0, r, 0, 0, _lib.IMPL_RING, st))
+                assert torch.equal(out, want[r][0][b0:b1]), (cols, r, slope)
 
 
 def test_segment_count_rounds_down(nz, gpu_device, monkeypatch):

@@ -155,3 +155,50 @@ def test_split_rotation_equals_alfa_rot_step():
         alfa_rest_step(b, sv)
         assert (t1_early, ir_early) == (a["t1"], a["inv_rho"]), it
         assert all(a[k] == b[k] or (a[k] != a[k] and b[k] != b[k]) for k in keys), (it, [(k, a[k], b[k]) for k in keys if a[k] != b[k]])
+
+
+def test_segment_rule_picks(tmp_path):
+    """csrc/seg_rule.h (round 5, profiles/r05_segment_balance.md): how a marching launch is cut into row segments, compiled
+    here with g++ and asked for the cases the note measures.  A large raster gets one full round of resident slots, rounded
+    DOWN (33 strips on 512 slots: 15 rows of segments = 495 workgroups, never 16 = 528); a small one gets the segment count
+    whose workgroups fill the 256 CUs k times exactly, without the old 4R minimum; the old rules stay reachable."""
+    import os
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "pick.cpp"
+    src.write_text('#include <cstdio>\n#include "seg_rule.h"\nint main() { int a[8]; '
+                   'while (std::scanf("%d %d %d %d %d %d %d %d", a, a + 1, a + 2, a + 3, a + 4, a + 5, a + 6, a + 7) == 8) '
+                   'std::printf("%d\\n", smrf_pick_nseg(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7])); return 0; }\n')
+    exe = tmp_path / "pick"
+    r = subprocess.run(["g++", "-O1", "-I", os.path.join(ROOT, "neilpy_amd", "csrc"), str(src), "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
+    #         rows   strips resident rounds warm batch min_seg rule   expected rows of segments
+    cases = [((16384, 64, 4, 1, 30, 6, 60, 0), 16),          # the benchmark raster: 1024 workgroups = every slot
+             ((16384, 64, 3, 1, 100, 4, 200, 0), 12),
+             ((8193, 33, 2, 1, 80, 4, 160, 0), 15),          # 495 of 512 slots, not 528
+             ((8193, 33, 2, 1, 80, 4, 160, 2), 15),
+             ((8193, 33, 2, 1, 80, 4, 160, 1), 16),          # rounds 1-4: to nearest -> a second, nearly empty round
+             ((30000, 24, 4, 1, 30, 6, 60, 0), 42),          # 1008 of 1024, not 43 x 24 = 1032
+             ((1024, 4, 3, 1, 100, 4, 200, 0), 64),          # 256 workgroups, one per CU, 16-row segments
+             ((1024, 4, 3, 1, 100, 4, 200, 2), 6),           # the 4R minimum: 24 workgroups
+             ((4096, 16, 2, 1, 100, 4, 200, 0), 32),         # 512 workgroups: two per CU exactly (measured best: 128 rows)
+             ((2048, 8, 2, 1, 100, 4, 200, 0), 32),          # one per CU, 64-row segments (measured best at R = 50)
+             ((2048, 64, 2, 1, 100, 4, 200, 0), 8),          # a 1/8 band of the benchmark: two per CU, 256 rows
+             ((100, 400, 3, 1, 100, 4, 200, 0), 1),          # more strips than slots: one row of segments
+             ((3, 1, 4, 1, 10, 4, 32, 0), 1),                # fewer rows than a batch
+             ((16384, 64, 4, 3, 6, 4, 32, 0), 48)]           # the chained launches keep their three rounds
+    out = subprocess.run([str(exe)], input="\n".join(" ".join(str(v) for v in c) for c, _ in cases) + "\n", capture_output=True,
+                         text=True, check=True).stdout.split()
+    assert [int(v) for v in out] == [w for _, w in cases], list(zip(out, cases))
+    # whatever the inputs: at least one, never more segments than batches of rows, and rule 0 never overfills the slots
+    import random
+    rnd = random.Random(5)
+    rand = [(rnd.randint(1, 40000), rnd.randint(1, 300), rnd.randint(1, 8), 1, rnd.randint(2, 128), rnd.choice((2, 4, 6, 8)), 32, 0)
+            for _ in range(2000)]
+    out = subprocess.run([str(exe)], input="\n".join(" ".join(str(v) for v in c) for c in rand) + "\n", capture_output=True,
+                         text=True, check=True).stdout.split()
+    for c, v in zip(rand, out):
+        nseg, (rows, strips, resident, _, _, batch, _, _) = int(v), c
+        assert 1 <= nseg <= max(1, rows // batch + 1), (c, nseg)
+        assert nseg == 1 or nseg * strips <= resident * 256, (c, nseg)
