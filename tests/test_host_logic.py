@@ -202,3 +202,34 @@ def test_segment_rule_picks(tmp_path):
         nseg, (rows, strips, resident, _, _, batch, _, _) = int(v), c
         assert 1 <= nseg <= max(1, rows // batch + 1), (c, nseg)
         assert nseg == 1 or nseg * strips <= resident * 256, (c, nseg)
+
+
+def test_power_sampler_reads_hwmon_files(tmp_path):
+    """tools/gpu_power.py (bench.py's roofline.power): the sampler thread reads power1_input (uW) / freq1_input (Hz) of a
+    hwmon directory and reports median / max watts and the median clock of a time span; without the files it says so
+    (bench.py then leaves the field out) instead of raising."""
+    import importlib.util
+    import os
+    import time
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gpu_power", os.path.join(ROOT, "tools", "gpu_power.py"))
+    gp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gp)
+    s = gp.Sampler.__new__(gp.Sampler)                       # (no torch device here: point it at a directory by hand)
+    gp.Sampler.__init__(s, device_index=0, period=0.005)
+    s.dir = str(tmp_path)
+    assert not s.ok and s.start().stop().between(0, time.time() + 1) is None
+    (tmp_path / "power1_input").write_text("1363000000\n")
+    (tmp_path / "power1_cap").write_text("1400000000\n")
+    (tmp_path / "freq1_input").write_text("2180000000\n")
+    assert s.ok and s.cap_w() == 1400.0
+    t0 = time.time()
+    s.start()
+    time.sleep(0.08)
+    (tmp_path / "power1_input").write_text("1378000000\n")
+    time.sleep(0.08)
+    s.stop()
+    r = s.between(t0, time.time())
+    assert r["samples"] >= 4 and r["socket_w_max"] == 1378.0 and 1363.0 <= r["socket_w"] <= 1378.0
+    assert abs(r["sclk_ghz"] - 2.18) < 1e-9
+    assert s.between(t0 - 10, t0 - 5) is None
