@@ -24,6 +24,7 @@ SmrfSwitches read_switches() {
   s.ring_rounds = env_int("SMRF_RING_ROUNDS", 1);
   s.ring_slope = env_int("SMRF_RING_SLOPE", -1);
   s.seg_rule = env_int("SMRF_SEG_RULE", 0);
+  s.xcd_remap = env_int("SMRF_XCD_REMAP", 1);
   s.fused_rounds = env_int("SMRF_FUSED_ROUNDS", 1);
   s.chain_rounds = env_int("SMRF_CHAIN_ROUNDS", 3);
   s.ring_debug = env_int("SMRF_RING_DEBUG", 0);

@@ -1290,11 +1290,22 @@ void ring_kernel(const DiskArgs<T> a) {
     }
   }
 #elif SMRF_RING_XCD_REMAP
-  if ((gridDim.x & 7) == 0) {
+  if (a.plain_tiles) {
+  } else if ((gridDim.x & 7) == 0) {
     const int id = blockIdx.y * gridDim.x + blockIdx.x, per = gridDim.x >> 3;
     const int xcd = id & 7, slot = id >> 3;
     bx = xcd * per + slot % per;
     by = slot / per;
+  } else if (gridDim.x > 8 && a.seg_cls == 0) {
+    // any other strip count (round 5): an XCD owns a contiguous range of the tiles taken strip by strip (a strip's segments
+    // together), i.e. strips / 8 neighbouring strips and parts of the two at its ends.  Without it the halo columns of a
+    // raster of arbitrary width came from HBM again: 8193 columns fetched 5.6-7.3 B per cell and erosion pass against
+    // 4.7-5.3 at 8192 (profiles/r05_segment_balance.md section 5).  XCD x gets ceil((total - x) / 8) of the workgroups.
+    const int total = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3, q = total >> 3, rem = total & 7;
+    const int t = xcd * q + (xcd < rem ? xcd : rem) + slot;
+    bx = t / (int)gridDim.y;
+    by = t % (int)gridDim.y;
   }
 #endif
 #ifdef SMRF_RING_DBG_CLOCK   // timing experiment only: the shader clock this workgroup ran at, left in the output's first two cells
@@ -1707,6 +1718,7 @@ int ring_launch_np(const DiskArgs<T>& a_in, hipStream_t stream, bool probe_only,
   // of its workgroups are), and the segments of class c get 1 + slope * ((classes - 1) / 2 - c) times the mean length.  Any
   // segmentation gives the same bits.
   a.seg_cls = 0;
+  a.plain_tiles = smrf_sw().xcd_remap ? 0 : 1;
   {
     // Measured (profiles/r05_segment_balance.md): -1.4 ... -2.1 % of the 16384^2 step at 60 permille per class (40 ... 100 are
     // within 0.3 % of it), nothing for fp64 (its classes differ by 3 %), and -1 ... +1 % where the classes do not fall on

@@ -43,6 +43,7 @@ struct SmrfSwitches {
   int seg_rule;       // SMRF_SEG_RULE: how a launch is cut into row segments (smrf_pick_nseg): 0 = by the cost model (default);
                       // 2 = one full round, rounds x resident x 256 / strips rounded down, segments >= 4R; 1 = rounded to nearest
                       // (rounds 1-4's rule)
+  int xcd_remap;      // SMRF_XCD_REMAP=0: no XCD-aware tile placement in the ring kernels (A/B runs)
   int ring_slope;     // SMRF_RING_SLOPE: permille of segment length per residency class (-1 = the library's rule, 0 = equal segments)
   int ring_debug;     // SMRF_RING_DEBUG: print each instance's geometry once
 };
@@ -91,6 +92,7 @@ struct DiskArgs {
   // See ring_launch_np.
   int seg_cls;
   int seg_first[8], seg_row0[8], seg_len[8];
+  int plain_tiles;    // 1: workgroup (x, y) takes tile (x, y) (SMRF_XCD_REMAP=0, A/B runs); 0: the XCD-aware placement of the kernel
 };
 
 // ring-kernel dispatchers, one per (dtype, radius % SMRF_RING_PARTS); defined in ring_part.hip.

@@ -233,3 +233,24 @@ def test_power_sampler_reads_hwmon_files(tmp_path):
     assert r["samples"] >= 4 and r["socket_w_max"] == 1378.0 and 1363.0 <= r["socket_w"] <= 1378.0
     assert abs(r["sclk_ghz"] - 2.18) < 1e-9
     assert s.between(t0 - 10, t0 - 5) is None
+
+
+def test_xcd_tile_placement_is_a_permutation():
+    """csrc/morph_ring.h ring_kernel (and lsqr_core.h lsqr_tile): workgroup `id` runs on XCD id % 8 and takes the tile
+    t = xcd * (total / 8) + min(xcd, total % 8) + id / 8 of the strip-major tile list, so that an XCD owns a contiguous range
+    of strips.  Restated here: every tile is taken exactly once for any grid, and an XCD's tiles are contiguous."""
+    import random
+    rnd = random.Random(3)
+    for gx, gy in [(33, 31), (17, 60), (47, 21), (9, 1), (129, 7)] + [(rnd.randint(9, 200), rnd.randint(1, 80)) for _ in range(40)]:
+        total = gx * gy
+        seen = set()
+        per_xcd = {}
+        for i in range(total):
+            xcd, slot, q, rem = i & 7, i >> 3, total >> 3, total & 7
+            t = xcd * q + min(xcd, rem) + slot
+            assert 0 <= t < total
+            seen.add((t // gy, t % gy))
+            per_xcd.setdefault(xcd, []).append(t)
+        assert len(seen) == total, (gx, gy)
+        for ts in per_xcd.values():
+            assert ts == list(range(ts[0], ts[0] + len(ts)))
