@@ -1270,6 +1270,10 @@ void ring_kernel(const DiskArgs<T> a) {
   using C = RingCfg<T, R, TW, NP>;
   using T2 = typename Vec2<T>::type;
   constexpr int WP = C::WP, ROWS = C::ROWS, NLEV = C::NLEV;
+  // fp64 with three row pairs per batch is NOT a validated configuration: a variant build that forced it gave wrong cells at
+  // R = 57, 58, 62, 63, 64 (512 registers + 240-290 B of scratch per lane; tools/ab_equal.py, profiles/r05_f64_np.md) while
+  // every shipped instance (<= 2 pairs) equals the oracle on every radius.  ring_tune.inc's fp64 caps keep it out.
+  static_assert(sizeof(T) == 4 || NP <= 2, "fp64 ring instances are validated for at most two row pairs per batch");
   extern __shared__ __attribute__((aligned(16))) unsigned char smrf_lds[];
   T2* const L = reinterpret_cast<T2*>(smrf_lds);         // [NP][NLEV][WP] of {row A, row B}
 
