@@ -59,8 +59,12 @@
 #endif
 // lookups per pipelined group: 4 for the small disks; 2 or 3 for the large ones, whose ring leaves
 // few registers for lookups in flight (measured per radius: tools/ring_tune.py --variants cur,g2,g3,g6)
+// fp64: per radius where ring_tune.inc says so (kRingGF64, round 5: the register rule below was written for fp32)
 #ifndef SMRF_RING_G
 #define SMRF_RING_G(ringregs) ((ringregs) > 132 ? 3 : (ringregs) > 100 ? 2 : 4)
+#define SMRF_RING_G_OF(T, R, ringregs) (ring_tuned_g<T>(R) > 0 ? ring_tuned_g<T>(R) : SMRF_RING_G(ringregs))
+#else
+#define SMRF_RING_G_OF(T, R, ringregs) SMRF_RING_G(ringregs)
 #endif
 // widths that may be looked up with three reads of the level below instead of building the top table level for them
 // (RingCfg::DROP_TOP); per radius, measured (gpurun_out/r02/ring_top3.log)
@@ -469,7 +473,7 @@ struct RingCfg {
   static constexpr bool INPLACE = INC && SMRF_RING_INPLACE(T, R) &&
                                   (!ring_tuned_inplace_dual<T>(R) || NP == SMRF_RING_INPLACE_NP(T, R));
   static constexpr int G = INPLACE && SMRF_RING_INPLACE_G(T, R) > 0 ? SMRF_RING_INPLACE_G(T, R)
-                                                                     : SMRF_RING_G(E * (2 * R + 2 * S::K));   // window lookups per pipelined group
+                                                                     : SMRF_RING_G_OF(T, R, E * (2 * R + 2 * S::K));   // window lookups per pipelined group
   static constexpr int NG = (S::K - 1 + G - 1) / G;      // groups for k = 1..K-1
   static constexpr int gsize(int g) { int n = S::K - 1 - g * G; return n < 0 ? 0 : (n > G ? G : n); }
   static constexpr int BASE_PB = SMRF_RING_BASE_PB(T, R) > 0 ? SMRF_RING_BASE_PB(T, R) : INPLACE ? 1 : 8;   // row pairs per round trip of the base-level build (in-place kernels are built for registers)
