@@ -187,7 +187,12 @@ def test_segment_rule_picks(tmp_path):
              ((2048, 64, 2, 1, 100, 4, 200, 0), 8),          # a 1/8 band of the benchmark: two per CU, 256 rows
              ((100, 400, 3, 1, 100, 4, 200, 0), 1),          # more strips than slots: one row of segments
              ((3, 1, 4, 1, 10, 4, 32, 0), 1),                # fewer rows than a batch
-             ((16384, 64, 4, 3, 6, 4, 32, 0), 48)]           # the chained launches keep their three rounds
+             ((16384, 64, 4, 3, 6, 4, 32, 0), 48),           # the chained launches keep their three rounds on the benchmark raster
+             ((16384, 64, 4, 3, 16, 4, 32, 0), 48),
+             ((8193, 33, 4, 3, 16, 4, 32, 0), 31),           # ... and take ONE round where that is cheaper (measured -6 %)
+             ((4096, 16, 4, 3, 16, 4, 32, 0), 64),
+             ((1024, 4, 4, 3, 16, 4, 32, 0), 64),
+             ((16384, 64, 4, 3, 16, 4, 32, 2), 48)]
     out = subprocess.run([str(exe)], input="\n".join(" ".join(str(v) for v in c) for c, _ in cases) + "\n", capture_output=True,
                          text=True, check=True).stdout.split()
     assert [int(v) for v in out] == [w for _, w in cases], list(zip(out, cases))
