@@ -1,3 +1,10 @@
+#!/usr/bin/env python3
+"""Bytes fetched per cell and ring pass from two `rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv` runs of
+tools/pmc_traffic.py (FETCH_SIZE in KiB, x 2.000: the calibration of profiles/pmc_summary.json), side by side per radius
+(timing experiment: profiles/r05_segment_balance.md section 5).
+
+    python tools/experiments/fetch_cmp.py <run A dir> <run B dir> <n of A> <n of B>
+"""
 import csv,re,collections,glob,sys
 def load(d):
     p=glob.glob(d+'/**/*counter_collection.csv',recursive=True)[0]
