@@ -1796,7 +1796,10 @@ int ring_launch(const DiskArgs<T>& a_in, hipStream_t stream) {
   if constexpr (ring_tuned_inplace_dual<T>(R) && SMRF_RING_INPLACE(T, R)) {
     // Both forms exist (ring_inpl.inc): the in-place instance runs one more workgroup per CU (3 or 4 waves per SIMD), worth
     // 3-7 % when its segments are long and a loss when they are not (more segments, each with 2R warm-up rows: +3...11 %
-    // on a 4096^2 raster or a 2048-row band).  Taken when the segments it would march are >= 16 R rows.
+    // on a 4096^2 raster or a 2048-row band).  Taken when the segments it would march are >= 8 R rows (16 R until round 5:
+    // measured on mid-size rasters, profiles/r05_logs/segments/dual.log - 10000 x 12000, 625-row segments: -7 ... -14 %
+    // at R = 40..50; 8193^2, 357 rows: -6 ... -7 % at R = 39..44 (8-9 R), +-1.5 % at 45..50 (7-8 R); 132..250-row
+    // segments of 5000^2, 4096^2 and a 2048-row band: +3 ... +10 % at R >= 45, i.e. 2.6-5 R).
     constexpr int NPI = SMRF_RING_INPLACE_NP(T, R);
     static_assert(NPI != NP, "a dual radius needs two different instances");
     static_assert(RingCfg<T, R, TW, NPI>::INPLACE && !RingCfg<T, R, TW, NP>::INPLACE, "dual instances mixed up");
@@ -1805,7 +1808,7 @@ int ring_launch(const DiskArgs<T>& a_in, hipStream_t stream) {
     if (mode != 0 && a_in.seg <= 0) {
       if (int rc = ring_launch_np<T, R, DIL, NPI>(a_in, stream, true, &seg)) return rc;
     }
-    if (mode == 1 || (mode < 0 && seg >= 16 * R)) return ring_launch_np<T, R, DIL, NPI>(a_in, stream, false, nullptr);
+    if (mode == 1 || (mode < 0 && seg >= 8 * R)) return ring_launch_np<T, R, DIL, NPI>(a_in, stream, false, nullptr);
   }
   return ring_launch_np<T, R, DIL, NP>(a_in, stream, false, nullptr);
 }
