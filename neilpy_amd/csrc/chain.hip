@@ -25,13 +25,21 @@ struct Pattern { int n; int r[4]; long long min_cells; long long min_cells_f64; 
 // 0.96 / 1.02 ms on 16384^2): the cell-by-cell window growth costs R min / max per row and stage where the table costs
 // K - 1 + ~3, and from R = 11 that outweighs the table's two extra barriers.  They do not exist.
 // The fp64 chain 1, 2, 3 (134 registers at one row pair per batch, 3 waves per SIMD): 0.578 against 0.615 ms for chain 1, 2 + the
-// fused R = 3 on 8192^2, slower on 4096^2 and 1024^2 (profiles/r04_logs/chain_123_f64_ab.log): from 48 Mi cells.
-constexpr long long kLarge = 48ll << 20;
+// fused R = 3 on 8192^2, slower on 4096^2 and 1024^2 (profiles/r04_logs/chain_123_f64_ab.log): from 48 Mi cells in round 4.
+// Round 5: the thresholds below were measured again after the launches' segmentation changed (seg_rule.h: one round cut by the
+// cost model on rasters this small; profiles/r05_logs/segments/min_cells_f32.log, min_cells_f64.log: default routing against
+// every kind that exists on 1024^2 ... 6000^2).  fp32: the chain 4, 5 wins from 5000^2 (-6 %, 6000^2 -11 %; loses 7-19 % on
+// 2048^2 and 4096^2), the singles R = 9, 10 win 17-27 % on 5000^2 and 6000^2; R = 9 also wins 9-13 % on 1024^2 ... 3000^2 and ties
+// on 4096^2 (any size now), R = 10 ties below 5000^2.  fp64: the chain
+// 1, 2, 3 and the single R = 5 win on every raster tried (-4 ... -16 %), R = 7 from 2048^2 (-7 %), R = 8 from 4096^2
+// (-11 ... -21 %; +10 ... +14 % below).
+constexpr long long kLarge = 20ll << 20;
 constexpr long long kMid = 16ll << 20;
+constexpr long long kSmall = 4ll << 20;
 constexpr long long kNever = -1;
-constexpr Pattern kPatterns[] = {{3, {1, 2, 3, 0}, 0, kLarge}, {2, {1, 2, 0, 0}, 0, 0}, {2, {2, 3, 0, 0}, 0, 0}, {2, {4, 5, 0, 0}, kLarge, kNever},
-                                 {1, {4, 0, 0, 0}, 0, 0}, {1, {5, 0, 0, 0}, 0, kLarge}, {1, {6, 0, 0, 0}, 0, kNever}, {1, {7, 0, 0, 0}, 0, kMid},
-                                 {1, {8, 0, 0, 0}, 0, kLarge}, {1, {9, 0, 0, 0}, kLarge, kNever}, {1, {10, 0, 0, 0}, kLarge, kNever}};
+constexpr Pattern kPatterns[] = {{3, {1, 2, 3, 0}, 0, 0}, {2, {1, 2, 0, 0}, 0, 0}, {2, {2, 3, 0, 0}, 0, 0}, {2, {4, 5, 0, 0}, kLarge, kNever},
+                                 {1, {4, 0, 0, 0}, 0, 0}, {1, {5, 0, 0, 0}, 0, 0}, {1, {6, 0, 0, 0}, 0, kNever}, {1, {7, 0, 0, 0}, 0, kSmall},
+                                 {1, {8, 0, 0, 0}, 0, kMid}, {1, {9, 0, 0, 0}, 0, kNever}, {1, {10, 0, 0, 0}, kLarge, kNever}};
 constexpr int kNPatterns = (int)(sizeof(kPatterns) / sizeof(kPatterns[0]));
 
 #ifndef SMRF_CHAIN_OCC

@@ -390,8 +390,10 @@ int progressive_filter_api(const T* Z, int rows, int cols, const int32_t* window
       continue;
     }
     // above R = 8 the fused kernel's 4R warm-up rows per segment only pay on rasters large enough for long segments
-    // (4096^2, windows 1..18: 1.64 ms with R <= 8 fused, 1.70 ms with 10..14 as well; 8192^2: 5.9 -> 5.2 ms with them)
-    if (fuse_ok && smrf_fused_radius((int)sizeof(T), r) && (r <= 8 || fuse_mode == 2 || plane >= ((size_t)48 << 20))) {
+    // (4096^2, windows 1..18: 1.64 ms with R <= 8 fused, 1.70 ms with 10..14 as well; 8192^2: 5.9 -> 5.2 ms with them);
+    // round 5, after the launches' segmentation changed: from 20 Mi cells (5000^2: R = 11..13 -7 ... -11 %, 6000^2 -10 ... -17 %,
+    // R = 14 equal; 4096^2 and below +3 ... +20 %: profiles/r05_logs/segments/min_cells_fused.log); 48 Mi until then
+    if (fuse_ok && smrf_fused_radius((int)sizeof(T), r) && (r <= 8 || fuse_mode == 2 || plane >= ((size_t)20 << 20))) {
       if (int rc = open_flag_api<T>(last, opened, mask, when, thr[i], i, rows, cols, cols, 0, rows, 0, rows, r, stream_, i == 0)) return rc;
       if (nwin > 1) last = opened;
       if (int rc = window_done(i, SMRF_ROUTE_FUSED)) return rc;

@@ -292,7 +292,7 @@ def progressive_filter_sharded(Z_band, img_rows, windows, thresholds, *, rank=No
             # theirs; not with NaNs (no NaN rule there) and not where the group's last window is split edge-first (overlap)
             if (world_size > 1 and not nan_aware and not overlap and hasattr(ops, "chain_len")):
                 # sized by the cells a launch of this group marches (a band plus its still-valid margin), not by the whole
-                # raster: the longer chains and the table-free R = 9, 10 only pay from 48 Mi cells up (chain.hip, min_cells).
+                # raster: the chain 4, 5 and the table-free R = 10 only pay from 20 Mi cells up (chain.hip, min_cells).
                 # The SAME figure on every rank - the longest band with a two-sided margin - so that all ranks route a
                 # window the same way (an edge rank's one-sided margin would otherwise put it on the other side of a size
                 # threshold than its neighbour; every route gives the same bits, but the ranks' launches should not differ).

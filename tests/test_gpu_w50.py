@@ -209,8 +209,8 @@ def test_window_routes(nz, gpu_device, monkeypatch):
 
     for name in ("SMRF_FUSED", "SMRF_CHAIN"):
         switch(monkeypatch, name, None)
-    m0, r0 = run()                                          # a small raster: chains 1-3, singles 4..8, fused none above 8
-    assert r0 == [C, C + 1, C + 2, C, C, C, C, C] + [_lib.ROUTE_TWO_PASS] * 8
+    m0, r0 = run()                            # a small raster: chains 1-3, singles 4..9 (9: any size since round 5), fused none above 8
+    assert r0 == [C, C + 1, C + 2, C, C, C, C, C, C] + [_lib.ROUTE_TWO_PASS] * 7
     switch(monkeypatch, "SMRF_FUSED", "2")                   # every launch kind that exists, whatever the size
     m2, r2 = run()
     assert r2 == [C, C + 1, C + 2, C, C + 1, C, C, C, C, C] + [_lib.ROUTE_FUSED] * 4 + [_lib.ROUTE_TWO_PASS] * 2
@@ -242,8 +242,8 @@ def test_window_routes_f64(nz, orc, gpu_device, monkeypatch):
 
     for name in ("SMRF_FUSED", "SMRF_CHAIN"):
         switch(monkeypatch, name, None)
-    m0, w0, r0 = run()                                      # a small raster: chain 1, 2; fused 3; single 4; fused 5, 6; two passes from 7
-    assert r0 == [C, C + 1, _lib.ROUTE_FUSED, C, _lib.ROUTE_FUSED, _lib.ROUTE_FUSED] + [_lib.ROUTE_TWO_PASS] * 4
+    m0, w0, r0 = run()     # a small raster (round 5's thresholds): chain 1, 2, 3; singles 4, 5; fused 6; two passes from 7 (single 7 from 4 Mi cells)
+    assert r0 == [C, C + 1, C + 2, C, C, _lib.ROUTE_FUSED] + [_lib.ROUTE_TWO_PASS] * 4
     switch(monkeypatch, "SMRF_FUSED", "2")                  # every launch kind that exists, whatever the size
     m2, w2, r2 = run()
     assert r2 == [C, C + 1, C + 2, C, C, _lib.ROUTE_FUSED, C, C] + [_lib.ROUTE_TWO_PASS] * 2   # chain 1, 2, 3; singles 4, 5, 7, 8
