@@ -295,7 +295,7 @@ int fused_launch(const DiskArgs<T>& a_in, hipStream_t stream) {
   const int strips = (a.cols + TWO - 1) / TWO;
   if (a.seg <= 0) {
     const int rounds = smrf_sw().fused_rounds;
-    // one round: every workgroup resident; a segment re-reads 4R warm-up rows (smrf_pick_nseg, smrf_common.h)
+    // one round: every workgroup resident; a segment re-reads 4R warm-up rows (smrf_pick_nseg, seg_rule.h)
     const int nseg = smrf_pick_nseg(a.out_rows, strips, resident, rounds, 4 * R, C::ROWS, std::max(32, 8 * R), smrf_sw().seg_rule);
     int seg = (a.out_rows + nseg - 1) / nseg;
     a.seg = seg;

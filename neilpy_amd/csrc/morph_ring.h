@@ -1708,7 +1708,7 @@ int ring_launch_np(const DiskArgs<T>& a_in, hipStream_t stream, bool probe_only,
     // output rows per workgroup: one round (every workgroup resident at once, the longest segments, the fewest re-read
     // halo rows) is the fastest from radius 20 up and as fast as any below (tools/ring_tune.py cur@SMRF_RING_ROUNDS=n);
     // how many rows of segments that round holds - all slots on a large raster, the CUs k times over on a small one -
-    // is smrf_pick_nseg's cost model (smrf_common.h)
+    // is smrf_pick_nseg's cost model (seg_rule.h)
     const int rounds = smrf_sw().ring_rounds;
     const int nseg = smrf_pick_nseg(a.out_rows, strips, resident, rounds, 2 * R, C::ROWS, std::max(32, 4 * R), smrf_sw().seg_rule);
     int seg = (a.out_rows + nseg - 1) / nseg;

@@ -313,7 +313,7 @@ def test_segment_count_rounds_down(nz, gpu_device, monkeypatch):
     nearest count - 33 strips x 16 segments = 528 workgroups on 512 slots ran 16 of them in a second round that lasted
     as long again (8193^2 fp32, all windows: 25.7 -> 21.8 ms; fp64: 99.9 -> 64.5 ms); and a raster too small to give
     every slot a long segment is cut so that its workgroups fill the CUs k times exactly (smrf_pick_nseg,
-    smrf_common.h).  SMRF_SEG_RULE=1 is rounds 1-4's rule, 2 the rounded-down full round with the 4R minimum: the same
+    seg_rule.h).  SMRF_SEG_RULE=1 is rounds 1-4's rule, 2 the rounded-down full round with the 4R minimum: the same
     bits under all three, on a raster whose strip count (33) makes them differ at most radii and on a small one."""
     import torch
     Z = torch.from_numpy(nz.synth_dem(8193, seed=32, rows=3000)).to(gpu_device)
