@@ -90,3 +90,35 @@ def test_drop_in_signatures_match_the_reference():
             assert (None if g.default is inspect.Parameter.empty else repr(g.default)) == p["default"], (name, g, p)
         for g in got[len(params):]:
             assert g.kind is inspect.Parameter.KEYWORD_ONLY, (name, g)
+
+
+def test_chain_length_size_thresholds():
+    """smrf_pf_chain_length is host logic (csrc/chain.hip min_cells): which small windows run as chained / table-free launches
+    depends on dtype and raster size.  Round 5 re-measured the thresholds under the new segmentation
+    (profiles/r05_segment_balance.md section 7): the chain 4, 5 and the single R = 10 from 20 Mi cells, the single R = 9 and
+    the fp64 chain 1, 2, 3 / single R = 5 at any size, the fp64 singles R = 7 / 8 from 4 / 16 Mi cells."""
+    import ctypes as C
+    import os
+    import numpy as np
+    from neilpy_amd import _lib
+    lib = _lib.load()
+    saved = {k: os.environ.pop(k, None) for k in ("SMRF_FUSED", "SMRF_CHAIN")}
+    _lib.reload_switches()
+    try:
+        def n(elem, radii, cells):
+            r = np.asarray(radii, dtype=np.int32)
+            return lib.smrf_pf_chain_length(elem, r.ctypes.data_as(C.c_void_p), len(r), cells)
+        Mi = 1 << 20
+        assert n(4, [1, 2, 3, 4], 1 * Mi) == 3 and n(4, [2, 3, 4], 1 * Mi) == 2 and n(4, [1, 2, 4], Mi) == 2
+        assert n(4, [4, 5, 6], 16 * Mi) == 1 and n(4, [4, 5, 6], 24 * Mi) == 2
+        assert n(4, [9, 10], 1 * Mi) == 1 and n(4, [10, 11], 16 * Mi) == 0 and n(4, [10, 11], 24 * Mi) == 1
+        assert n(4, [11], 1 << 40) == 0 and n(4, [6], 1) == 1
+        assert n(8, [1, 2, 3], 1 * Mi) == 3 and n(8, [5], 1 * Mi) == 1 and n(8, [4, 5], 1 << 40) == 1     # no fp64 chain 4, 5
+        assert n(8, [7], 2 * Mi) == 0 and n(8, [7], 4 * Mi) == 1
+        assert n(8, [8], 8 * Mi) == 0 and n(8, [8], 16 * Mi) == 1
+        assert n(8, [6], 1 << 40) == 0 and n(8, [9], 1 << 40) == 0
+    finally:
+        for k, v in saved.items():
+            if v is not None:
+                os.environ[k] = v
+        _lib.reload_switches()
