@@ -468,9 +468,11 @@ int chain_launch(const ChainArgs<T>& a_in, hipStream_t stream) {
   ChainArgs<T> a = a_in;
   const int strips = (a.cols + C::TWO - 1) / C::TWO;
   if (a.seg <= 0) {
-    // three workgroups per resident slot: the workgroups a CU really holds can be fewer than the occupancy query says
-    // (chain 4, 5: 2.4 waves per SIMD measured where 4 were expected), and a launch sized for exactly one round then
-    // runs a second, mostly empty one; with three the tail is short whatever the residency (chain 4, 5: 1.17 -> 0.87 ms)
+    // Asks for three workgroups per resident slot (round 3: chain 4, 5 on 16384^2 1.17 -> 0.87 ms - the counters showed 2.4
+    // waves per SIMD where 4 were expected: with what round 5's per-workgroup timestamps show, that was a one-round launch's
+    // tail - its youngest workgroups end 3 % per residency class behind - and, at the time, a second, nearly empty round
+    // whenever the segment count rounded up).  smrf_pick_nseg (seg_rule.h) weighs the three rounds against the best single
+    // round and takes the cheaper: three on the benchmark raster, one below ~10^8 cells.
     const int rounds = smrf_sw().chain_rounds;
     const int nseg = smrf_pick_nseg(a.out_rows, strips, resident, rounds, 2 * C::S, C::ROWS, std::max(32, 4 * C::S), smrf_sw().seg_rule);
     int seg = (a.out_rows + nseg - 1) / nseg;
