@@ -257,9 +257,11 @@ def secondary(dev):
     spec = importlib.util.spec_from_file_location("smrf_stages", os.path.join(ROOT, "tools", "smrf_stages.py"))
     st = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(st)
-    out["smrf_20M"] = st.run(points=20_000_000, extent=8192.0, windows=18, cellsize=1.0)
+    out["smrf_20M"] = st.run(points=20_000_000, extent=8192.0, windows=18, cellsize=1.0, warm=True)
     out["smrf_20M"]["workload"] = ("neilpy_amd.smrf on synth_points(2e7, 8192.0, seed=20241), cellsize 1, windows 18, "
-                                   "device-resident points in, device tensors out")
+                                   "device-resident points in, device tensors out; the per-stage figures are each stage's SECOND "
+                                   "run (a first run also loads kernels, queries occupancies and grows the allocator: "
+                                   "create_dem 15 ms cold, 1.5 ms warm), smrf_total_ms one whole call after them")
     torch.cuda.empty_cache()
     n, nw = 8192, 18
     Z = torch.from_numpy(neilpy_amd.synth_dem(n, seed=20240, dtype=np.float64)).to(dev)
